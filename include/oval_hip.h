@@ -1,0 +1,223 @@
+/*
+ * oval_hip.h — C ABI of the MI355X (gfx950) data-pattern engine.
+ *
+ * This is the boundary a cgo file in the reference's internal/pattern package
+ * binds.  The reference has no FFI of its own (it is built CGO_ENABLED=0,
+ * Makefile:23); the entry points below replace the bodies of
+ *
+ *   pattern.Generate          internal/pattern/pattern.go:73-92
+ *   pattern.generateDataUnit  internal/pattern/pattern.go:94-116
+ *   pattern.Valid             internal/pattern/pattern.go:118-134
+ *   pattern.validDataUnit     internal/pattern/pattern.go:136-180
+ *
+ * for whole batches of objects at a time.  Plain pointers and sizes only; no
+ * C++ or torch types.  Every function returns OVAL_OK (0) or a negative
+ * oval_status; on failure a human-readable message is available from
+ * oval_last_error() on the calling thread.  Nothing throws across this ABI.
+ *
+ * All structures are little-endian and fixed-width.  No pointer passed in is
+ * retained after the call returns unless the function says so.
+ */
+#ifndef OVAL_HIP_H
+#define OVAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants of the data unit (pattern.go:17-20, object.go:13-19) ---- */
+#define OVAL_UNIT_SIZE        256u  /* dataUnitSize */
+#define OVAL_MAX_BUCKET_LEN   16u   /* object.MaxBucketNameLength */
+#define OVAL_MAX_KEY_LEN      12u   /* object.MaxKeyLength */
+#define OVAL_HEADER_SIZE      48u   /* 16 + 12 + dataUnitHeaderSizeWithoutBucketAndKey */
+#define OVAL_NO_BAD_UNIT      0xFFFFFFFFu
+
+/* Bits of a per-unit field mask.  Bits 0..4 are the five checks of
+ * validDataUnit in the order it reports them (pattern.go:140-170); bit 5 is
+ * this engine's opt-in extension: some byte of [48,256) differs from its own
+ * offset.  The reference never looks at bytes >= 40. */
+#define OVAL_BAD_BUCKET   0x01u
+#define OVAL_BAD_KEY      0x02u
+#define OVAL_BAD_WRITECNT 0x04u
+#define OVAL_BAD_OFFSET   0x08u
+#define OVAL_BAD_WORKER   0x10u
+#define OVAL_BAD_FILLER   0x20u
+#define OVAL_REF_FIELDS   0x1Fu
+
+typedef enum oval_status {
+    OVAL_OK            =  0,
+    OVAL_E_INVALID     = -1,  /* bad argument (null, misaligned, out of range) */
+    OVAL_E_HIP         = -2,  /* a HIP runtime call failed                    */
+    OVAL_E_NOMEM       = -3,  /* host or device allocation failed             */
+    OVAL_E_LAYOUT      = -4,  /* descriptors overlap / unsorted / misaligned  */
+    OVAL_E_FIELD       = -5,  /* bucket+key do not format to exactly 28 bytes */
+    OVAL_E_RANGE       = -6,  /* body buffer smaller than the layout needs    */
+    OVAL_E_NODEVICE    = -7   /* no gfx950 device visible                     */
+} oval_status;
+
+/*
+ * One object of a batch: the expected state the reference keeps in
+ * object.Object (object.go:21-25) plus where its body lives in the batch
+ * buffer.  Bytes [0,48) are literally the header of the object's unit 0 as
+ * generateDataUnit writes it (pattern.go:95-107), except that [32,36) holds
+ * first_unit instead of a byte offset.
+ */
+typedef struct oval_obj_desc {
+    uint8_t  bucket[16];   /* "%-16s" of the (<=16-byte) bucket name           */
+    uint8_t  key[12];      /* "%-12s" of obj.Key                                */
+    uint32_t write_count;  /* uint32(obj.WriteCount)                            */
+    uint32_t first_unit;   /* unit index (unitCount) of this body's first unit;
+                              0 for a whole object, >0 for a part of a stream   */
+    uint32_t worker_id;    /* uint32(workerID)                                  */
+    uint64_t unix_micro;   /* pinned time.Now().UnixMicro(); never validated    */
+    uint64_t body_offset;  /* byte offset of the first unit in the batch buffer;
+                              multiple of 256                                   */
+    uint32_t n_units;      /* number of 256-byte units to fill / validate       */
+    uint8_t  bucket_len;   /* byte length of the expected bucket name (<=16)    */
+    uint8_t  key_len;      /* byte length of the expected key (<=12)            */
+    uint16_t flags;        /* OVAL_DESC_* (set by oval_desc_init)               */
+} oval_obj_desc;           /* 64 bytes */
+
+/* The expected name has leading or trailing Unicode white space, so
+ * strings.TrimSpace(field) can never equal it (pattern.go:140,147): every unit
+ * must take the exact TrimSpace check instead of the 128-bit compare. */
+#define OVAL_DESC_BUCKET_SLOW 0x0001u
+#define OVAL_DESC_KEY_SLOW    0x0002u
+
+/* Per-object outcome of a validate pass.  first_bad_unit is the unitCount at
+ * which Valid would have returned its error (pattern.go:128-131): the lowest
+ * unit with any of the five reference fields wrong, OVAL_NO_BAD_UNIT if none.
+ * The first two words form one little-endian u64 (unit in the high half). */
+typedef struct oval_obj_result {
+    uint32_t first_bad_fields;      /* OVAL_BAD_* (bits 0..4) of that unit; 0xFFFFFFFF if none */
+    uint32_t first_bad_unit;        /* reference semantics                         */
+    uint32_t bad_units;             /* units with a reference-visible mismatch     */
+    uint32_t strict_first_bad_unit; /* lowest unit with ANY mismatch outside the
+                                       time bytes [40,48), filler included         */
+} oval_obj_result;                  /* 16 bytes */
+
+/* Batch-wide counters: the vector that is summed across GPUs. */
+enum {
+    OVAL_CNT_OBJECTS_CHECKED = 0,
+    OVAL_CNT_OBJECTS_BAD     = 1,
+    OVAL_CNT_UNITS_CHECKED   = 2,
+    OVAL_CNT_UNITS_BAD       = 3,
+    OVAL_CNT_BAD_BUCKET      = 4,
+    OVAL_CNT_BAD_KEY         = 5,
+    OVAL_CNT_BAD_WRITECNT    = 6,
+    OVAL_CNT_BAD_OFFSET      = 7,
+    OVAL_CNT_BAD_WORKER      = 8,
+    OVAL_CNT_STRICT_UNITS_BAD = 9,
+    OVAL_CNT_RESERVED0       = 10,
+    OVAL_CNT_RESERVED1       = 11,
+    OVAL_NUM_COUNTERS        = 12
+};
+
+typedef struct oval_ctx    oval_ctx;     /* one device + one stream          */
+typedef struct oval_layout oval_layout;  /* device-resident descriptor table */
+
+/* ---- process-wide ------------------------------------------------------ */
+const char* oval_last_error(void);            /* thread-local, never NULL     */
+const char* oval_version(void);
+int oval_device_count(int* n_out);
+
+/* ---- context ------------------------------------------------------------
+ * A context binds one device and one stream.  `stream` is a hipStream_t cast
+ * to void*; NULL makes the context create (and own) a non-blocking stream.
+ * A context is used by one host thread at a time; several contexts may run
+ * concurrently (one per goroutine-pinned OS thread, or one per GPU). */
+int oval_ctx_create(int device_id, void* stream, oval_ctx** out);
+int oval_ctx_destroy(oval_ctx* ctx);
+int oval_ctx_sync(oval_ctx* ctx);
+int oval_ctx_stream(oval_ctx* ctx, void** stream_out);
+
+/* ---- memory the host side may need --------------------------------------
+ * Pinned host buffers are what a cgo caller wraps with unsafe.Slice: Go memory
+ * may not be handed to an asynchronous copy. */
+int oval_dev_alloc(oval_ctx* ctx, size_t bytes, void** dptr_out);
+int oval_dev_free(oval_ctx* ctx, void* dptr);
+int oval_pinned_alloc(oval_ctx* ctx, size_t bytes, void** hptr_out);
+int oval_pinned_free(oval_ctx* ctx, void* hptr);
+int oval_copy_h2d(oval_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* async on the ctx stream */
+int oval_copy_d2h(oval_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* async on the ctx stream */
+
+/* ---- descriptors --------------------------------------------------------
+ * Host-side helper that applies the reference's formatting rules: bucket is
+ * cut to its first 16 bytes (pattern.go:74-76,119-121) and both names are
+ * left-justified and space padded like fmt's "%-16s%-12s" (pattern.go:95,98).
+ * Returns OVAL_E_FIELD when the two fields do not come to exactly 28 bytes
+ * (key longer than 12 bytes, or non-ASCII names whose rune count differs from
+ * their byte count): the reference's Generate then fails its length check
+ * (pattern.go:87-89). write_count and worker_id are truncated to 32 bits as
+ * the reference's uint32() conversions do (pattern.go:101,105). */
+int oval_desc_init(oval_obj_desc* d,
+                   const char* bucket, size_t bucket_len,
+                   const char* key, size_t key_len,
+                   int64_t write_count, int64_t worker_id, uint64_t unix_micro,
+                   uint64_t body_offset, uint32_t first_unit, uint32_t n_units);
+
+/* ---- layout -------------------------------------------------------------
+ * Uploads `n_obj` descriptors and builds the device-side chunk index.
+ * Requirements (checked; OVAL_E_LAYOUT otherwise): body_offset is a multiple
+ * of 256 and bodies are in ascending, non-overlapping order (gaps and
+ * zero-unit objects are allowed).  The layout can be used for any number of
+ * fill / validate passes and owns all device memory it needs, so those passes
+ * allocate nothing. */
+int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs_host, uint64_t n_obj,
+                       oval_layout** out);
+int oval_layout_destroy(oval_ctx* ctx, oval_layout* layout);
+int oval_layout_info(const oval_layout* layout, uint64_t* n_obj, uint64_t* total_units,
+                     uint64_t* span_bytes);
+
+/* ---- the two kernels ----------------------------------------------------
+ * oval_fill: writes every unit of every object of the layout into body_dev
+ * (device memory, 256-byte aligned, >= span_bytes long).  Replaces the loop
+ * of Generate over generateDataUnit (pattern.go:79-85,94-116).
+ *
+ * oval_validate: reads every unit once, regenerates the expected unit in
+ * registers and writes one oval_obj_result per object (device memory,
+ * results_dev[n_obj]) plus, if counters_dev is not NULL, ADDS the batch totals
+ * into counters_dev[OVAL_NUM_COUNTERS] (device memory, caller zeroes it).
+ * Replaces the loop of Valid over validDataUnit (pattern.go:123-132,136-180).
+ * Both are asynchronous on the context's stream. */
+int oval_fill(oval_ctx* ctx, const oval_layout* layout, void* body_dev, uint64_t body_bytes);
+int oval_validate(oval_ctx* ctx, const oval_layout* layout, const void* body_dev,
+                  uint64_t body_bytes, oval_obj_result* results_dev, uint64_t* counters_dev);
+
+/* Copies the 256 bytes at body_dev + byte_offset to out256 (host) and waits:
+ * the unit the host needs to format the reference's error text
+ * (pattern.go:141-175). */
+int oval_read_unit(oval_ctx* ctx, const void* body_dev, uint64_t byte_offset, uint8_t* out256);
+
+/* ---- one-shot helpers for bodies that start and end in host memory -------
+ * body_host may be pinned (fast path) or pageable.  They create a temporary
+ * layout, stage through device memory in chunks with copies overlapped on a
+ * second stream, and wait for completion.  results_host[n_obj] and
+ * counters_host[OVAL_NUM_COUNTERS] (may be NULL) are host memory. */
+int oval_fill_batch_host(oval_ctx* ctx, const oval_obj_desc* descs_host, uint64_t n_obj,
+                         void* body_host, uint64_t body_bytes);
+int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs_host, uint64_t n_obj,
+                             const void* body_host, uint64_t body_bytes,
+                             oval_obj_result* results_host, uint64_t* counters_host);
+
+/* ---- kernel launch tuning (benchmarks only) ------------------------------
+ * blocks_per_cu <= 0 restores the default. */
+int oval_ctx_set_tuning(oval_ctx* ctx, int blocks_per_cu, int variant);
+
+/* ---- timing --------------------------------------------------------------
+ * HIP events recorded on the context's stream, for callers (bench.py) that
+ * launch through this ABI and therefore cannot use another runtime's events. */
+typedef struct oval_timer oval_timer;
+int oval_timer_create(oval_ctx* ctx, oval_timer** out);
+int oval_timer_destroy(oval_timer* t);
+int oval_timer_start(oval_ctx* ctx, oval_timer* t);
+int oval_timer_stop(oval_ctx* ctx, oval_timer* t);
+int oval_timer_elapsed_ms(oval_timer* t, float* ms_out);  /* waits for stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVAL_HIP_H */
