@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: device-resident pattern generate+validate GB/s.
+
+One step = one fill pass + one validate pass over one resident batch of
+synthetic objects (default: 1,000,000 objects of 4k-16k per GPU, sizes by
+DecideSize, pinned unix time), followed for N > 1 by the single all-reduce of
+the counter vector.  Objects shard by worker key range: rank r owns the key
+space of process ID r (64 workers), so no body byte crosses GPUs and scaling
+is weak.  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+T0 = 1709558129112997          # README.md:105, the pinned unix time (microseconds)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+WORKLOADS = {
+    # name: (objects per GPU, workers, min size, max size, description)
+    "cfg2": (1_000_000, 64, 4096, 16384, "1M objects 4k-16k (DecideSize), fill+validate batch"),
+    "cfg3": (64, 64, 256 << 20, 256 << 20, "64 objects x 256 MiB, fill+validate"),
+    "cfg5": (1_250_000, 50, 4096, 1 << 20, "resident batches of 4k-1M objects"),
+}
+
+
+def build_batch(name, rank, n_obj_override, seed):
+    from oval_amd.batch import WorkerSpace, synthetic_batch
+
+    n_obj, n_worker, lo, hi, _ = WORKLOADS[name]
+    if n_obj_override:
+        n_obj = n_obj_override
+    n_worker = min(n_worker, n_obj)
+    n_obj -= n_obj % n_worker
+    space = WorkerSpace(num_obj=n_obj, num_worker=n_worker, runner_id=rank, start_worker_id=0x561B)
+    return synthetic_batch(space, range(n_worker), "test-bucket", lo, hi, seed=seed, unix_micro=T0)
+
+
+def cpu_baseline(descs, budget_s, threads):
+    """The oracle (a C port of the reference's pattern.go) on this host's cores,
+    over a bounded prefix of the same batch: fill then validate, per slice."""
+    from oracle import oracle as O
+    from oval_amd.batch import span_bytes
+
+    O.build()
+    D = descs.view(O.DESC_DTYPE)
+    slice_objs = max(1, min(len(descs), 20000))
+
+    def run_slice(lo, out):
+        d = D[lo:lo + slice_objs].copy()
+        d["body_offset"] -= d["body_offset"][0]
+        body = np.empty(span_bytes(d), dtype=np.uint8)
+        t = time.perf_counter()
+        O.fill_batch(d, body)
+        res, _ = O.validate_batch(d, body)
+        dt = time.perf_counter() - t
+        assert (res["first_bad_unit"] == O.NO_BAD).all()
+        out.append((int(d["n_units"].sum()), dt))
+
+    done, t_start, lo = [], time.perf_counter(), 0
+    while lo < len(descs) and time.perf_counter() - t_start < budget_s:
+        ths, outs = [], []
+        for _ in range(threads):
+            if lo >= len(descs):
+                break
+            o = []
+            th = threading.Thread(target=run_slice, args=(lo, o))
+            th.start()
+            ths.append(th); outs.append(o)
+            lo += slice_objs
+        for th in ths:
+            th.join()
+        done += [o[0] for o in outs]
+    wall = time.perf_counter() - t_start
+    units = sum(u for u, _ in done)
+    return {
+        "value": round(512.0 * units / wall / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
+        "sample": f"oracle fill+validate of the first {min(lo, len(descs))} objects ({units} units, "
+                  f"{units * 256 / 1e9:.2f} GB) of the same batch, {wall:.1f} s, {threads} thread(s)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--objects", type=int, default=0, help="objects per GPU (default: the workload's)")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+
+    from oval_amd import engine
+    from oval_amd.batch import span_bytes
+    from oval_amd.dist import all_reduce_counters
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the pattern engine has no CPU path")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    stream = torch.cuda.Stream(local)
+    torch.cuda.set_stream(stream)
+    ctx = engine.Context(local, stream.cuda_stream)
+    ctx.set_tuning(args.blocks_per_cu, args.variant)
+
+    descs = build_batch(args.workload, rank, args.objects, args.seed)
+    n_obj, units = len(descs), int(descs["n_units"].sum())
+    nbytes = span_bytes(descs)
+    layout = engine.Layout(ctx, descs)
+    body = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local}")
+    results = torch.empty((n_obj, 4), dtype=torch.int32, device=body.device)
+    counters = torch.zeros(engine.NUM_COUNTERS, dtype=torch.int64, device=body.device)
+
+    def step(tf=None, tv=None):
+        counters.zero_()
+        if tf: tf.start()
+        layout.fill(body)
+        if tf: tf.stop()
+        if tv: tv.start()
+        layout.validate(body, results, counters)
+        if tv: tv.stop()
+        all_reduce_counters(counters)          # the one collective of a batch
+
+    for _ in range(args.warmup):
+        step()
+    timers = [(engine.Timer(ctx), engine.Timer(ctx)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for tf, tv in timers:
+        step(tf, tv)
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+
+    fill_ms = float(np.mean([tf.elapsed_ms() for tf, _ in timers]))
+    val_ms = float(np.mean([tv.elapsed_ms() for _, tv in timers]))
+    tot = counters.cpu().numpy()
+    stats = torch.tensor([wall, float(units)], dtype=torch.float64, device=body.device)
+    if dist:
+        mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        wall, units_all = float(mx[0]), float(sm[1])
+    else:
+        units_all = float(units)
+    # the batch was clean: nothing may be reported bad, everything must have been checked
+    assert int(tot[1]) == 0 and int(tot[3]) == 0, f"clean batch reported corrupt: {tot}"
+    assert int(tot[2]) == int(units_all), (int(tot[2]), units_all)
+
+    if rank == 0:
+        ms_per_step = wall / args.steps * 1e3
+        value = 512.0 * units_all / (wall / args.steps) / 1e9
+        fill_gbs = 256.0 * units / (fill_ms / 1e3) / 1e9
+        val_gbs = 256.0 * units / (val_ms / 1e3) / 1e9
+        dom, dom_ms, dom_gbs = ("validate_kernel", val_ms, val_gbs) if val_ms >= fill_ms else ("fill_kernel", fill_ms, fill_gbs)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "device-resident pattern generate+validate GB/s",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][4]}", "objects_per_gpu": n_obj,
+                       "units_per_gpu": units, "bytes_per_gpu": nbytes, "sharding": "worker key range (process ID = rank)",
+                       "blocks_per_cu": args.blocks_per_cu or 8, "variant": args.variant},
+            "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": 256 * units, "avg_launch_ms": round(dom_ms, 4)},
+            "kernels": {"fill_ms": round(fill_ms, 4), "fill_GBps": round(fill_gbs, 1),
+                        "validate_ms": round(val_ms, 4), "validate_GBps": round(val_gbs, 1)},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(descs, args.cpu_seconds, 1)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

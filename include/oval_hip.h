@@ -86,6 +86,13 @@ typedef struct oval_obj_desc {
  * must take the exact TrimSpace check instead of the 128-bit compare. */
 #define OVAL_DESC_BUCKET_SLOW 0x0001u
 #define OVAL_DESC_KEY_SLOW    0x0002u
+/* The expected worker ID does not fit a uint32: validDataUnit compares it as a
+ * Go int (pattern.go:166-167), so no unit can ever match. */
+#define OVAL_DESC_WORKER_OOR  0x0004u
+/* The names hold multi-byte runes, so "%-16s%-12s" pads them past 28 bytes and
+ * the reference's Generate fails its length check (pattern.go:87-89).  Such an
+ * object can be validated (the fields are compared as bytes) but not filled. */
+#define OVAL_DESC_NO_FILL     0x0008u
 
 /* Per-object outcome of a validate pass.  first_bad_unit is the unitCount at
  * which Valid would have returned its error (pattern.go:128-131): the lowest
@@ -148,10 +155,9 @@ int oval_copy_d2h(oval_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
  * Host-side helper that applies the reference's formatting rules: bucket is
  * cut to its first 16 bytes (pattern.go:74-76,119-121) and both names are
  * left-justified and space padded like fmt's "%-16s%-12s" (pattern.go:95,98).
- * Returns OVAL_E_FIELD when the two fields do not come to exactly 28 bytes
- * (key longer than 12 bytes, or non-ASCII names whose rune count differs from
- * their byte count): the reference's Generate then fails its length check
- * (pattern.go:87-89). write_count and worker_id are truncated to 32 bits as
+ * Returns OVAL_E_FIELD for a key longer than 12 bytes ("%-12s" never
+ * truncates, so no 256-byte unit exists for it) and sets OVAL_DESC_NO_FILL for
+ * names whose rune count differs from their byte count. write_count and worker_id are truncated to 32 bits as
  * the reference's uint32() conversions do (pattern.go:101,105). */
 int oval_desc_init(oval_obj_desc* d,
                    const char* bucket, size_t bucket_len,
@@ -168,6 +174,10 @@ int oval_desc_init(oval_obj_desc* d,
  * allocate nothing. */
 int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs_host, uint64_t n_obj,
                        oval_layout** out);
+/* Replaces the contents of an existing layout with a new descriptor set,
+ * reusing its device memory when it is large enough (no allocation then). */
+int oval_layout_reset(oval_ctx* ctx, oval_layout* layout, const oval_obj_desc* descs_host,
+                      uint64_t n_obj);
 int oval_layout_destroy(oval_ctx* ctx, oval_layout* layout);
 int oval_layout_info(const oval_layout* layout, uint64_t* n_obj, uint64_t* total_units,
                      uint64_t* span_bytes);

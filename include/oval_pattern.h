@@ -1,0 +1,79 @@
+/*
+ * oval_pattern.h — C entry points of the host-side mirror of the reference's
+ * internal/pattern and internal/object packages.
+ *
+ * The mirror itself is C++ (oval_amd/csrc/oval_pattern.hpp: namespaces
+ * oval::object and oval::pattern with the reference's function names).  These
+ * wrappers exist so that a language without a C++ FFI (ctypes in the tests, or
+ * cgo) can call it; each one names the reference function it stands for.
+ * Names are passed as pointer + length because Go strings may hold any bytes.
+ *
+ * Return value convention for the functions that return a Go `error` in the
+ * reference: 0 = nil, 1 = an error whose text (exactly the reference's) was
+ * written to `err` (NUL-terminated, truncated to err_cap), negative = the
+ * engine itself failed (oval_status; text from oval_last_error()).
+ */
+#ifndef OVAL_PATTERN_H
+#define OVAL_PATTERN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Creates the process-wide engine on `device_id` (idempotent). */
+int oval_pattern_init(int device_id);
+void oval_pattern_shutdown(void);
+
+/* time.Now().UnixMicro() as Generate sees it (pattern.go:103-104).  A value
+ * >= 0 pins the clock (every unit of a call gets this value); < 0 returns to
+ * the wall clock, sampled once per Generate call. */
+void oval_pattern_set_clock(int64_t unix_micro);
+/* Seeds the generator behind DecideSize's rand.Float64() (pattern.go:63). */
+void oval_pattern_seed(uint64_t seed);
+
+/* pattern.DecideSize — pattern.go:22-71 */
+int oval_pattern_decide_size(int64_t min_size, int64_t max_size, int64_t* size_out,
+                             char* err, size_t err_cap);
+/* the same with the uniform sample y in [0,1) supplied by the caller */
+int oval_pattern_decide_size_y(int64_t min_size, int64_t max_size, double y, int64_t* size_out,
+                               char* err, size_t err_cap);
+
+/* pattern.Generate — pattern.go:73-92.  out must hold data_size bytes. */
+int oval_pattern_generate(int64_t data_size, int64_t worker_id,
+                          const char* bucket, size_t bucket_len,
+                          const char* key, size_t key_len, int64_t write_count,
+                          uint8_t* out, char* err, size_t err_cap);
+
+/* pattern.generateDataUnit — pattern.go:94-116.  out must hold 256 bytes. */
+int oval_pattern_generate_data_unit(int64_t unit_count, int64_t worker_id,
+                                    const char* bucket, size_t bucket_len,
+                                    const char* key, size_t key_len, int64_t write_count,
+                                    uint8_t* out, char* err, size_t err_cap);
+
+/* pattern.Valid — pattern.go:118-134.  The io.Reader is the byte range
+ * body[0, body_len); obj.Size is `size`. */
+int oval_pattern_valid(int64_t worker_id, const char* bucket, size_t bucket_len,
+                       const char* key, size_t key_len, int64_t size, int64_t write_count,
+                       const uint8_t* body, size_t body_len, char* err, size_t err_cap);
+
+/* pattern.validDataUnit — pattern.go:136-180.  data holds 256 bytes. */
+int oval_pattern_valid_data_unit(int64_t unit_count, int64_t worker_id,
+                                 const char* bucket, size_t bucket_len,
+                                 const char* key, size_t key_len, int64_t write_count,
+                                 const uint8_t* data, char* err, size_t err_cap);
+
+/* pattern.dump — pattern.go:182-206; and encoding/hex.Dump which feeds it.
+ * Both return the full length of the text and write at most cap-1 bytes + NUL. */
+size_t oval_pattern_dump(const char* text, size_t n, char* out, size_t cap);
+size_t oval_pattern_hex_dump(const uint8_t* data, size_t n, char* out, size_t cap);
+
+/* object.generateKey — object.go:48-50.  Returns the key length. */
+size_t oval_object_generate_key(int64_t obj_id, char* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVAL_PATTERN_H */

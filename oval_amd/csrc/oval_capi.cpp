@@ -1,0 +1,600 @@
+// oval_capi.cpp — implementation of the C ABI declared in include/oval_hip.h.
+//
+// There is no CPU implementation behind this ABI: every fill and validate goes
+// through the gfx950 kernels, and a process without a usable device gets
+// OVAL_E_NODEVICE / OVAL_E_HIP, never a silent fallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/oval_hip.h"
+#include "oval_kernels.h"
+#include "oval_gostr.h"
+#include "oval_trimspace.h"
+
+static_assert(sizeof(oval_obj_desc) == 64, "descriptor must be 64 bytes");
+static_assert(offsetof(oval_obj_desc, key) == 16, "layout");
+static_assert(offsetof(oval_obj_desc, write_count) == 28, "layout");
+static_assert(offsetof(oval_obj_desc, first_unit) == 32, "layout");
+static_assert(offsetof(oval_obj_desc, worker_id) == 36, "layout");
+static_assert(offsetof(oval_obj_desc, unix_micro) == 40, "layout");
+static_assert(offsetof(oval_obj_desc, body_offset) == 48, "layout");
+static_assert(offsetof(oval_obj_desc, n_units) == 56, "layout");
+static_assert(offsetof(oval_obj_desc, bucket_len) == 60, "layout");
+static_assert(offsetof(oval_obj_desc, flags) == 62, "layout");
+static_assert(sizeof(oval_obj_result) == 16, "result must be 16 bytes");
+
+struct oval_ctx {
+    int         device      = 0;
+    hipStream_t stream      = nullptr;
+    bool        own_stream  = false;
+    hipStream_t copy_stream = nullptr;   // second stream for overlapped host copies
+    int         n_cu        = 256;
+    int         blocks_per_cu = 8;
+    int         variant     = 0;
+};
+
+struct oval_layout {
+    int       device = 0;
+    void*     descs_dev = nullptr;
+    uint32_t* chunk_first_dev = nullptr;
+    uint64_t  n_obj = 0;
+    uint64_t  total_units = 0;
+    uint64_t  span_bytes = 0;
+    uint32_t  n_chunks = 0;
+    bool      no_fill = false;   // some descriptor carries OVAL_DESC_NO_FILL
+    uint64_t  cap_obj = 0;       // descriptors the device table can hold
+    uint32_t  cap_chunks = 0;    // entries the chunk table can hold
+};
+
+struct oval_timer {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP,           \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                  \
+    } while (0)
+
+oval::LayoutView view_of(const oval_layout* l)
+{
+    oval::LayoutView v;
+    v.descs = l->descs_dev;
+    v.chunk_first = l->chunk_first_dev;
+    v.n_obj = (uint32_t)l->n_obj;
+    v.n_chunks = l->n_chunks;
+    v.span_units = (uint32_t)(l->span_bytes / OVAL_UNIT_SIZE);
+    v.total_units = l->total_units;
+    return v;
+}
+
+oval::LaunchCfg cfg_of(const oval_ctx* c)
+{
+    oval::LaunchCfg k;
+    k.grid_blocks = c->n_cu * c->blocks_per_cu;
+    k.variant = c->variant;
+    return k;
+}
+
+uint32_t tiles_of(const oval_layout* l)
+{
+    return (l->n_chunks + oval::kChunksPerTile - 1) / oval::kChunksPerTile;
+}
+
+// true when strings.TrimSpace(name) != name, i.e. the expected name itself
+// starts or ends with white space
+bool go_space_at_edges(const unsigned char* s, size_t n)
+{
+    int a, b;
+    oval::trim_space([&](int i) { return (uint32_t)s[i]; }, (int)n, a, b);
+    return !(a == 0 && b == (int)n);
+}
+}  // namespace
+
+extern "C" {
+
+const char* oval_last_error(void) { return g_err.c_str(); }
+
+const char* oval_version(void) { return "oval_hip 0.1 (gfx950)"; }
+
+int oval_device_count(int* n_out)
+{
+    if (!n_out) return fail(OVAL_E_INVALID, "n_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *n_out = 0; return fail(OVAL_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n_out = n;
+    return OVAL_OK;
+}
+
+int oval_ctx_create(int device_id, void* stream, oval_ctx** out)
+{
+    if (!out) return fail(OVAL_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(OVAL_E_NODEVICE, "no HIP device is visible; the pattern engine has no CPU path");
+    if (device_id < 0 || device_id >= n) return fail(OVAL_E_INVALID, "device %d out of range [0,%d)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(OVAL_E_NODEVICE, "device %d is %s; this library carries gfx950 code only", device_id,
+                    prop.gcnArchName);
+    oval_ctx* c = new (std::nothrow) oval_ctx;
+    if (!c) return fail(OVAL_E_NOMEM, "out of host memory");
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(OVAL_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(OVAL_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return OVAL_OK;
+}
+
+int oval_ctx_destroy(oval_ctx* ctx)
+{
+    if (!ctx) return OVAL_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return OVAL_OK;
+}
+
+int oval_ctx_sync(oval_ctx* ctx)
+{
+    if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return OVAL_OK;
+}
+
+int oval_ctx_stream(oval_ctx* ctx, void** stream_out)
+{
+    if (!ctx || !stream_out) return fail(OVAL_E_INVALID, "NULL argument");
+    *stream_out = (void*)ctx->stream;
+    return OVAL_OK;
+}
+
+int oval_ctx_set_tuning(oval_ctx* ctx, int blocks_per_cu, int variant)
+{
+    if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
+    ctx->blocks_per_cu = blocks_per_cu > 0 ? (blocks_per_cu > 64 ? 64 : blocks_per_cu) : 8;
+    ctx->variant = variant < 0 ? 0 : variant;
+    return OVAL_OK;
+}
+
+int oval_dev_alloc(oval_ctx* ctx, size_t bytes, void** dptr_out)
+{
+    if (!ctx || !dptr_out) return fail(OVAL_E_INVALID, "NULL argument");
+    *dptr_out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(dptr_out, bytes ? bytes : 1));
+    return OVAL_OK;
+}
+
+int oval_dev_free(oval_ctx* ctx, void* dptr)
+{
+    if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
+    if (!dptr) return OVAL_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipFree(dptr));
+    return OVAL_OK;
+}
+
+int oval_pinned_alloc(oval_ctx* ctx, size_t bytes, void** hptr_out)
+{
+    if (!ctx || !hptr_out) return fail(OVAL_E_INVALID, "NULL argument");
+    *hptr_out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipHostMalloc(hptr_out, bytes ? bytes : 1, hipHostMallocDefault));
+    return OVAL_OK;
+}
+
+int oval_pinned_free(oval_ctx* ctx, void* hptr)
+{
+    if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
+    if (!hptr) return OVAL_OK;
+    HIP_TRY(hipHostFree(hptr));
+    return OVAL_OK;
+}
+
+int oval_copy_h2d(oval_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
+{
+    if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return fail(OVAL_E_INVALID, "NULL argument");
+    if (!bytes) return OVAL_OK;
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return OVAL_OK;
+}
+
+int oval_copy_d2h(oval_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes)
+{
+    if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return fail(OVAL_E_INVALID, "NULL argument");
+    if (!bytes) return OVAL_OK;
+    HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return OVAL_OK;
+}
+
+int oval_desc_init(oval_obj_desc* d, const char* bucket, size_t bucket_len, const char* key,
+                   size_t key_len, int64_t write_count, int64_t worker_id, uint64_t unix_micro,
+                   uint64_t body_offset, uint32_t first_unit, uint32_t n_units)
+{
+    if (!d || (!bucket && bucket_len) || (!key && key_len)) return fail(OVAL_E_INVALID, "NULL argument");
+    const unsigned char* b = (const unsigned char*)bucket;
+    const unsigned char* k = (const unsigned char*)key;
+    if (bucket_len > OVAL_MAX_BUCKET_LEN) bucket_len = OVAL_MAX_BUCKET_LEN;   // pattern.go:74-76,119-121
+    if (key_len > OVAL_MAX_KEY_LEN)
+        return fail(OVAL_E_FIELD, "key is %zu bytes; \"%%-12s\" does not truncate, the unit would not be 256 bytes", key_len);
+    // fmt "%-16s%-12s" (pattern.go:95,98) pads to a RUNE count
+    const size_t bfield = oval::go_padded_len(b, bucket_len, OVAL_MAX_BUCKET_LEN);
+    const size_t kfield = oval::go_padded_len(k, key_len, OVAL_MAX_KEY_LEN);
+    if (body_offset % OVAL_UNIT_SIZE) return fail(OVAL_E_INVALID, "body_offset %llu is not a multiple of 256",
+                                                  (unsigned long long)body_offset);
+    std::memset(d, 0, sizeof *d);
+    std::memset(d->bucket, ' ', sizeof d->bucket);
+    std::memset(d->key, ' ', sizeof d->key);
+    std::memcpy(d->bucket, b, bucket_len);
+    std::memcpy(d->key, k, key_len);
+    d->write_count = (uint32_t)write_count;   // pattern.go:101,154
+    d->first_unit = first_unit;
+    d->worker_id = (uint32_t)worker_id;       // pattern.go:105
+    d->unix_micro = unix_micro;
+    d->body_offset = body_offset;
+    d->n_units = n_units;
+    d->bucket_len = (uint8_t)bucket_len;
+    d->key_len = (uint8_t)key_len;
+    uint16_t flags = 0;
+    if (go_space_at_edges(b, bucket_len)) flags |= OVAL_DESC_BUCKET_SLOW;
+    if (go_space_at_edges(k, key_len)) flags |= OVAL_DESC_KEY_SLOW;
+    // validDataUnit compares the worker ID as a Go int (pattern.go:166-167): a
+    // value outside uint32 can never equal what the unit holds
+    if (worker_id < 0 || worker_id > 0xFFFFFFFFll) flags |= OVAL_DESC_WORKER_OOR;
+    // names with multi-byte runes pad past their field in the reference, whose
+    // Generate then fails (pattern.go:87-89): such an object can be validated
+    // but must not be filled
+    if (bfield != OVAL_MAX_BUCKET_LEN || kfield != OVAL_MAX_KEY_LEN) flags |= OVAL_DESC_NO_FILL;
+    d->flags = flags;
+    return OVAL_OK;
+}
+
+// Checks a descriptor set and computes its totals.
+static int scan_descs(const oval_obj_desc* descs, uint64_t n_obj, uint64_t* total_units_out,
+                      uint64_t* span_bytes_out, bool* no_fill_out)
+{
+    bool no_fill = false;
+    if (n_obj >= 0xFFFFFFF0ull) return fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
+    uint64_t prev_end = 0, total_units = 0;
+    for (uint64_t i = 0; i < n_obj; ++i) {
+        const oval_obj_desc& d = descs[i];
+        if (d.body_offset % OVAL_UNIT_SIZE)
+            return fail(OVAL_E_LAYOUT, "object %llu: body_offset %llu is not a multiple of 256",
+                        (unsigned long long)i, (unsigned long long)d.body_offset);
+        if (d.body_offset < prev_end)
+            return fail(OVAL_E_LAYOUT, "object %llu: body at %llu overlaps or precedes the previous object (ends %llu)",
+                        (unsigned long long)i, (unsigned long long)d.body_offset, (unsigned long long)prev_end);
+        if (d.bucket_len > OVAL_MAX_BUCKET_LEN || d.key_len > OVAL_MAX_KEY_LEN)
+            return fail(OVAL_E_LAYOUT, "object %llu: name lengths %u/%u exceed 16/12", (unsigned long long)i,
+                        d.bucket_len, d.key_len);
+        prev_end = d.body_offset + (uint64_t)d.n_units * OVAL_UNIT_SIZE;
+        total_units += d.n_units;
+        no_fill |= (d.flags & OVAL_DESC_NO_FILL) != 0;
+        if (prev_end / OVAL_UNIT_SIZE >= 0xFFFFFF00ull)
+            return fail(OVAL_E_LAYOUT, "batch spans %llu bytes; the limit is just under 1 TiB",
+                        (unsigned long long)prev_end);
+    }
+    *no_fill_out = no_fill;
+    *total_units_out = total_units;
+    *span_bytes_out = prev_end;
+    return OVAL_OK;
+}
+
+int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj)
+{
+    if (!ctx || !l || (!descs && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
+    if (l->device != ctx->device) return fail(OVAL_E_INVALID, "layout belongs to device %d, context to %d", l->device, ctx->device);
+    uint64_t total_units = 0, span_bytes = 0;
+    bool no_fill = false;
+    int rc = scan_descs(descs, n_obj, &total_units, &span_bytes, &no_fill);
+    if (rc) return rc;
+    const uint64_t span_units = span_bytes / OVAL_UNIT_SIZE;
+    const uint32_t n_chunks = (uint32_t)((span_units + oval::kUnitsPerChunk - 1) / oval::kUnitsPerChunk);
+    HIP_TRY(hipSetDevice(ctx->device));
+    // a pass that still uses the old tables must finish before they are replaced
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_obj > l->cap_obj || !l->descs_dev) {
+        if (l->descs_dev) { (void)hipFree(l->descs_dev); l->descs_dev = nullptr; l->cap_obj = 0; }
+        const uint64_t cap = n_obj ? n_obj : 1;
+        HIP_TRY(hipMalloc(&l->descs_dev, cap * sizeof(oval_obj_desc)));
+        l->cap_obj = cap;
+    }
+    if (n_chunks > l->cap_chunks || !l->chunk_first_dev) {
+        if (l->chunk_first_dev) { (void)hipFree(l->chunk_first_dev); l->chunk_first_dev = nullptr; l->cap_chunks = 0; }
+        const uint32_t cap = n_chunks ? n_chunks : 1;
+        HIP_TRY(hipMalloc((void**)&l->chunk_first_dev, (size_t)cap * 4));
+        l->cap_chunks = cap;
+    }
+    l->n_obj = n_obj;
+    l->no_fill = no_fill;
+    l->total_units = total_units;
+    l->span_bytes = span_bytes;
+    l->n_chunks = n_chunks;
+    if (n_obj)
+        HIP_TRY(hipMemcpyAsync(l->descs_dev, descs, n_obj * sizeof(oval_obj_desc), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(oval::launch_build_chunk_table(ctx->stream, l->descs_dev, (uint32_t)n_obj, l->chunk_first_dev, n_chunks));
+    // the caller's descriptor array may be pageable and is not retained: wait for the upload
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return OVAL_OK;
+}
+
+int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, oval_layout** out)
+{
+    if (!ctx || !out || (!descs && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
+    *out = nullptr;
+    oval_layout* l = new (std::nothrow) oval_layout;
+    if (!l) return fail(OVAL_E_NOMEM, "out of host memory");
+    l->device = ctx->device;
+    int rc = oval_layout_reset(ctx, l, descs, n_obj);
+    if (rc) {
+        if (l->descs_dev) (void)hipFree(l->descs_dev);
+        if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
+        delete l;
+        return rc;
+    }
+    *out = l;
+    return OVAL_OK;
+}
+
+int oval_layout_destroy(oval_ctx* ctx, oval_layout* l)
+{
+    if (!l) return OVAL_OK;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (l->descs_dev) (void)hipFree(l->descs_dev);
+    if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
+    delete l;
+    return OVAL_OK;
+}
+
+int oval_layout_info(const oval_layout* l, uint64_t* n_obj, uint64_t* total_units, uint64_t* span_bytes)
+{
+    if (!l) return fail(OVAL_E_INVALID, "layout is NULL");
+    if (n_obj) *n_obj = l->n_obj;
+    if (total_units) *total_units = l->total_units;
+    if (span_bytes) *span_bytes = l->span_bytes;
+    return OVAL_OK;
+}
+
+static int check_body(const oval_ctx* ctx, const oval_layout* l, const void* body, uint64_t body_bytes)
+{
+    if (!ctx || !l) return fail(OVAL_E_INVALID, "NULL argument");
+    if (l->device != ctx->device) return fail(OVAL_E_INVALID, "layout belongs to device %d, context to %d", l->device, ctx->device);
+    if (l->span_bytes && !body) return fail(OVAL_E_INVALID, "body is NULL");
+    if (((uintptr_t)body) % 256) return fail(OVAL_E_INVALID, "body pointer %p is not 256-byte aligned", body);
+    if (body_bytes < l->span_bytes)
+        return fail(OVAL_E_RANGE, "body holds %llu bytes but the layout spans %llu",
+                    (unsigned long long)body_bytes, (unsigned long long)l->span_bytes);
+    return OVAL_OK;
+}
+
+int oval_fill(oval_ctx* ctx, const oval_layout* l, void* body_dev, uint64_t body_bytes)
+{
+    int rc = check_body(ctx, l, body_dev, body_bytes);
+    if (rc) return rc;
+    if (l->no_fill)
+        return fail(OVAL_E_FIELD, "the layout holds an object whose names do not format to 28 bytes; "
+                                  "the reference's Generate fails for it (pattern.go:87-89)");
+    HIP_TRY(oval::launch_fill(ctx->stream, cfg_of(ctx), view_of(l), body_dev, 0, tiles_of(l)));
+    return OVAL_OK;
+}
+
+int oval_validate(oval_ctx* ctx, const oval_layout* l, const void* body_dev, uint64_t body_bytes,
+                  oval_obj_result* results_dev, uint64_t* counters_dev)
+{
+    int rc = check_body(ctx, l, body_dev, body_bytes);
+    if (rc) return rc;
+    if (!results_dev && l->n_obj) return fail(OVAL_E_INVALID, "results_dev is NULL");
+    if (((uintptr_t)results_dev) % 16) return fail(OVAL_E_INVALID, "results_dev is not 16-byte aligned");
+    if (((uintptr_t)counters_dev) % 8) return fail(OVAL_E_INVALID, "counters_dev is not 8-byte aligned");
+    const oval::LayoutView v = view_of(l);
+    HIP_TRY(oval::launch_init_results(ctx->stream, v, results_dev, (unsigned long long*)counters_dev));
+    HIP_TRY(oval::launch_validate(ctx->stream, cfg_of(ctx), v, body_dev, 0, tiles_of(l), results_dev,
+                                  (unsigned long long*)counters_dev));
+    return OVAL_OK;
+}
+
+int oval_read_unit(oval_ctx* ctx, const void* body_dev, uint64_t byte_offset, uint8_t* out256)
+{
+    if (!ctx || !body_dev || !out256) return fail(OVAL_E_INVALID, "NULL argument");
+    if (byte_offset % OVAL_UNIT_SIZE) return fail(OVAL_E_INVALID, "byte_offset is not a multiple of 256");
+    HIP_TRY(hipMemcpyAsync(out256, (const char*)body_dev + byte_offset, OVAL_UNIT_SIZE, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return OVAL_OK;
+}
+
+// ---- bodies in host memory: stage through the device in slices -------------
+// A slice is a whole number of tiles (64 KiB each); the kernel for slice k runs
+// on the main stream while the copy of slice k-1 (fill) or k+1 (validate) runs
+// on the copy stream.
+namespace {
+constexpr uint64_t kTileBytes = (uint64_t)oval::kUnitsPerChunk * oval::kChunksPerTile * OVAL_UNIT_SIZE;
+constexpr uint32_t kSliceTiles = 512;   // 32 MiB
+}
+
+int oval_fill_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, void* body_host,
+                         uint64_t body_bytes)
+{
+    if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
+    oval_layout* l = nullptr;
+    int rc = oval_layout_create(ctx, descs, n_obj, &l);
+    if (rc) return rc;
+    if (body_bytes < l->span_bytes || (!body_host && l->span_bytes)) {
+        oval_layout_destroy(ctx, l);
+        return fail(OVAL_E_RANGE, "host body holds %llu bytes but the layout spans %llu",
+                    (unsigned long long)body_bytes, (unsigned long long)l->span_bytes);
+    }
+    void* dev = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipError_t e = hipMalloc(&dev, l->span_bytes ? l->span_bytes : 256);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    const uint32_t n_tiles = tiles_of(l);
+    const oval::LayoutView v = view_of(l);
+    uint32_t k = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles, ++k) {
+        const uint32_t t1 = t0 + kSliceTiles < n_tiles ? t0 + kSliceTiles : n_tiles;
+        e = oval::launch_fill(ctx->stream, cfg_of(ctx), v, dev, t0, t1);
+        if (e == hipSuccess) e = hipEventRecord(ev[k & 1], ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ev[k & 1], 0);
+        const uint64_t b0 = (uint64_t)t0 * kTileBytes;
+        uint64_t b1 = (uint64_t)t1 * kTileBytes;
+        if (b1 > l->span_bytes) b1 = l->span_bytes;
+        if (e == hipSuccess && b1 > b0)
+            e = hipMemcpyAsync((char*)body_host + b0, (const char*)dev + b0, b1 - b0, hipMemcpyDeviceToHost,
+                               ctx->copy_stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+    for (int i = 0; i < 2; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (dev) (void)hipFree(dev);
+    oval_layout_destroy(ctx, l);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "fill_batch_host: %s", hipGetErrorString(e));
+    return OVAL_OK;
+}
+
+int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj,
+                             const void* body_host, uint64_t body_bytes, oval_obj_result* results_host,
+                             uint64_t* counters_host)
+{
+    if (!ctx || (!results_host && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
+    oval_layout* l = nullptr;
+    int rc = oval_layout_create(ctx, descs, n_obj, &l);
+    if (rc) return rc;
+    if (body_bytes < l->span_bytes || (!body_host && l->span_bytes)) {
+        oval_layout_destroy(ctx, l);
+        return fail(OVAL_E_RANGE, "host body holds %llu bytes but the layout spans %llu",
+                    (unsigned long long)body_bytes, (unsigned long long)l->span_bytes);
+    }
+    void* dev = nullptr;
+    oval_obj_result* res_dev = nullptr;
+    unsigned long long* cnt_dev = nullptr;
+    std::vector<hipEvent_t> evs;
+    hipError_t e = hipMalloc(&dev, l->span_bytes ? l->span_bytes : 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&res_dev, n_obj ? n_obj * sizeof(oval_obj_result) : 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&cnt_dev, OVAL_NUM_COUNTERS * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(cnt_dev, 0, OVAL_NUM_COUNTERS * 8, ctx->stream);
+    const uint32_t n_tiles = tiles_of(l);
+    const oval::LayoutView v = view_of(l);
+    if (e == hipSuccess) e = oval::launch_init_results(ctx->stream, v, res_dev, cnt_dev);
+    for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles) {
+        const uint32_t t1 = t0 + kSliceTiles < n_tiles ? t0 + kSliceTiles : n_tiles;
+        const uint64_t b0 = (uint64_t)t0 * kTileBytes;
+        uint64_t b1 = (uint64_t)t1 * kTileBytes;
+        if (b1 > l->span_bytes) b1 = l->span_bytes;
+        hipEvent_t ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) break;
+        evs.push_back(ev);
+        if (b1 > b0)
+            e = hipMemcpyAsync((char*)dev + b0, (const char*)body_host + b0, b1 - b0, hipMemcpyHostToDevice,
+                               ctx->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(ev, ctx->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+        if (e == hipSuccess) e = oval::launch_validate(ctx->stream, cfg_of(ctx), v, dev, t0, t1, res_dev, cnt_dev);
+    }
+    if (e == hipSuccess && n_obj)
+        e = hipMemcpyAsync(results_host, res_dev, n_obj * sizeof(oval_obj_result), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && counters_host)
+        e = hipMemcpyAsync(counters_host, cnt_dev, OVAL_NUM_COUNTERS * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+    if (dev) (void)hipFree(dev);
+    if (res_dev) (void)hipFree(res_dev);
+    if (cnt_dev) (void)hipFree(cnt_dev);
+    oval_layout_destroy(ctx, l);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "validate_batch_host: %s", hipGetErrorString(e));
+    return OVAL_OK;
+}
+
+// ---- timing -----------------------------------------------------------------
+int oval_timer_create(oval_ctx* ctx, oval_timer** out)
+{
+    if (!ctx || !out) return fail(OVAL_E_INVALID, "NULL argument");
+    *out = nullptr;
+    oval_timer* t = new (std::nothrow) oval_timer;
+    if (!t) return fail(OVAL_E_NOMEM, "out of host memory");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = hipEventCreate(&t->start);
+    if (e == hipSuccess) e = hipEventCreate(&t->stop);
+    if (e != hipSuccess) { delete t; return fail(OVAL_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+    *out = t;
+    return OVAL_OK;
+}
+
+int oval_timer_destroy(oval_timer* t)
+{
+    if (!t) return OVAL_OK;
+    if (t->start) (void)hipEventDestroy(t->start);
+    if (t->stop) (void)hipEventDestroy(t->stop);
+    delete t;
+    return OVAL_OK;
+}
+
+int oval_timer_start(oval_ctx* ctx, oval_timer* t)
+{
+    if (!ctx || !t) return fail(OVAL_E_INVALID, "NULL argument");
+    HIP_TRY(hipEventRecord(t->start, ctx->stream));
+    return OVAL_OK;
+}
+
+int oval_timer_stop(oval_ctx* ctx, oval_timer* t)
+{
+    if (!ctx || !t) return fail(OVAL_E_INVALID, "NULL argument");
+    HIP_TRY(hipEventRecord(t->stop, ctx->stream));
+    return OVAL_OK;
+}
+
+int oval_timer_elapsed_ms(oval_timer* t, float* ms_out)
+{
+    if (!t || !ms_out) return fail(OVAL_E_INVALID, "NULL argument");
+    HIP_TRY(hipEventSynchronize(t->stop));
+    HIP_TRY(hipEventElapsedTime(ms_out, t->start, t->stop));
+    return OVAL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// oval_pattern.hpp — host-side mirror of the reference's Go packages
+// internal/object and internal/pattern, in front of the HIP engine.
+//
+// Names, argument meaning and error text follow the reference so that its
+// callers (internal/runner/worker.go:64,77,85,109,140,200) and its tests
+// (internal/pattern/pattern_test.go) read the same against this API.  A Go
+// `error` becomes an oval::Error: `nil()` is Go's nil, otherwise `msg` is what
+// err.Error() would return.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace oval {
+
+struct Error {
+    bool ok = true;
+    std::string msg;
+    bool nil() const { return ok; }
+    static Error Nil() { return Error{}; }
+    static Error New(std::string m) { Error e; e.ok = false; e.msg = std::move(m); return e; }
+};
+
+namespace object {
+
+// internal/object/object.go:13-19
+constexpr int MaxBucketNameLength = 16;
+constexpr int MaxKeyLength = 12;
+constexpr const char* KeyShortPrefix = "ov";
+constexpr int KeyPrefixLength = 6;
+
+// internal/object/object.go:21-25
+struct Object {
+    std::string Key;
+    int64_t Size = 0;
+    int64_t WriteCount = 0;
+    void Clear() { Size = 0; WriteCount = 0; }   // object.go:35-38
+};
+
+std::string generateKey(int64_t objID);          // object.go:48-50
+Object NewObject(int64_t objID);                 // object.go:40-46
+
+}  // namespace object
+
+namespace pattern {
+
+constexpr int dataUnitSize = 256;                          // pattern.go:18
+constexpr int dataUnitHeaderSizeWithoutBucketAndKey = 20;  // pattern.go:19
+
+// io.Reader: returns the number of bytes read into p (<= n); 0 means EOF.
+class Reader {
+public:
+    virtual ~Reader() = default;
+    virtual size_t Read(uint8_t* p, size_t n) = 0;
+};
+
+// bytes.NewReader
+class BytesReader : public Reader {
+public:
+    BytesReader(const uint8_t* data, size_t len) : p_(data), n_(len) {}
+    size_t Read(uint8_t* p, size_t n) override;
+private:
+    const uint8_t* p_;
+    size_t n_;
+    size_t pos_ = 0;
+};
+
+// pattern.go:22-71
+std::pair<int64_t, Error> DecideSize(int64_t minSize, int64_t maxSize);
+std::pair<int64_t, Error> DecideSizeFrom(int64_t minSize, int64_t maxSize, double y);
+
+// pattern.go:73-92
+std::pair<std::vector<uint8_t>, Error> Generate(int64_t dataSize, int64_t workerID,
+                                                const std::string& bucketName,
+                                                const object::Object* obj);
+// the same into caller-provided memory (dataSize bytes)
+Error GenerateInto(int64_t dataSize, int64_t workerID, const std::string& bucketName,
+                   const object::Object* obj, uint8_t* out);
+
+// pattern.go:94-116
+std::pair<std::vector<uint8_t>, Error> generateDataUnit(int64_t unitCount, int64_t workerID,
+                                                        const std::string& bucketName,
+                                                        const object::Object* obj);
+
+// pattern.go:118-134
+Error Valid(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
+            Reader& reader);
+
+// pattern.go:136-180
+Error validDataUnit(int64_t unitCount, int64_t workerID, const std::string& expectedBucketName,
+                    const object::Object* obj, const uint8_t* data /* 256 bytes */);
+
+// pattern.go:182-206 and encoding/hex.Dump
+std::string dump(const std::string& data);
+std::string hexDump(const uint8_t* data, size_t n);
+
+// Engine control (no counterpart in the reference).
+int  Init(int deviceID);            // oval_status
+void Shutdown();
+void SetClock(int64_t unixMicro);   // >= 0 pins time.Now().UnixMicro(); < 0 = wall clock
+void Seed(uint64_t seed);           // source of rand.Float64() in DecideSize
+const std::string& LastEngineError();
+
+}  // namespace pattern
+}  // namespace oval

@@ -1,0 +1,199 @@
+"""Batch engine: thin object wrappers over the C ABI (include/oval_hip.h).
+
+Device memory and streams come from PyTorch (plumbing only): a body is a 1-D
+uint8 CUDA tensor, results a (n_obj, 4) int32/uint32-viewed tensor, counters a
+(12,) int64 tensor that torch.distributed can all-reduce over RCCL.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DESC_DTYPE, NUM_COUNTERS, RESULT_DTYPE, UNIT, OvalError, check
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = _lib.lib().oval_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Context:
+    """One device + one stream (oval_ctx)."""
+
+    def __init__(self, device: int = 0, stream_ptr: int | None = None):
+        self._h = C.c_void_p()
+        check(_lib.lib().oval_ctx_create(device, C.c_void_p(stream_ptr or 0), C.byref(self._h)))
+        self.device = device
+
+    @classmethod
+    def on_torch_stream(cls, device: int = 0):
+        """Context whose stream is torch's current stream on `device`, so that
+        torch ops and engine launches are ordered with each other."""
+        import torch
+
+        with torch.cuda.device(device):
+            cur = torch.cuda.current_stream(device)
+            keep = None
+            if not cur.cuda_stream:
+                # torch is on the null stream, which the ABI reads as "create
+                # your own": give torch a real stream and share that one
+                keep = torch.cuda.Stream(device)
+                torch.cuda.set_stream(keep)
+                cur = keep
+            ctx = cls(device, cur.cuda_stream)
+            ctx._torch_stream = cur      # keeps the stream alive as long as the context
+        return ctx
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_tuning(self, blocks_per_cu: int = 0, variant: int = 0) -> None:
+        check(_lib.lib().oval_ctx_set_tuning(self._h, blocks_per_cu, variant))
+
+    def sync(self) -> None:
+        check(_lib.lib().oval_ctx_sync(self._h))
+
+    def stream_ptr(self) -> int:
+        p = C.c_void_p()
+        check(_lib.lib().oval_ctx_stream(self._h, C.byref(p)))
+        return p.value or 0
+
+    def close(self) -> None:
+        if self._h:
+            _lib.lib().oval_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- one-shot helpers for host-resident bodies ---------------------------
+    def fill_batch_host(self, descs: np.ndarray, body: np.ndarray) -> None:
+        _check_descs(descs)
+        assert body.dtype == np.uint8 and body.flags.c_contiguous
+        check(_lib.lib().oval_fill_batch_host(self._h, descs.ctypes.data, len(descs), body.ctypes.data, body.size))
+
+    def validate_batch_host(self, descs: np.ndarray, body: np.ndarray):
+        _check_descs(descs)
+        assert body.dtype == np.uint8 and body.flags.c_contiguous
+        res = np.empty(len(descs), dtype=RESULT_DTYPE)
+        cnt = np.zeros(NUM_COUNTERS, dtype=np.uint64)
+        check(_lib.lib().oval_validate_batch_host(self._h, descs.ctypes.data, len(descs), body.ctypes.data,
+                                                  body.size, res.ctypes.data, cnt.ctypes.data))
+        return res, cnt
+
+
+def _check_descs(descs: np.ndarray) -> None:
+    if descs.dtype != DESC_DTYPE or not descs.flags.c_contiguous:
+        raise OvalError("descriptors must be a C-contiguous array of DESC_DTYPE")
+
+
+class Layout:
+    """Device-resident descriptor table + chunk index (oval_layout)."""
+
+    def __init__(self, ctx: Context, descs: np.ndarray):
+        _check_descs(descs)
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        check(_lib.lib().oval_layout_create(ctx.handle, descs.ctypes.data, len(descs), C.byref(self._h)))
+        self._read_info()
+
+    def _read_info(self):
+        n, u, s = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(_lib.lib().oval_layout_info(self._h, C.byref(n), C.byref(u), C.byref(s)))
+        self.n_obj, self.total_units, self.span_bytes = n.value, u.value, s.value
+
+    def reset(self, descs: np.ndarray) -> None:
+        _check_descs(descs)
+        check(_lib.lib().oval_layout_reset(self.ctx.handle, self._h, descs.ctypes.data, len(descs)))
+        self._read_info()
+
+    def close(self) -> None:
+        if self._h:
+            _lib.lib().oval_layout_destroy(self.ctx.handle, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the two kernels ------------------------------------------------------
+    def fill(self, body) -> None:
+        """body: 1-D uint8 CUDA tensor of at least span_bytes bytes."""
+        _check_body(body, self.ctx.device)
+        check(_lib.lib().oval_fill(self.ctx.handle, self._h, body.data_ptr(), body.numel()))
+
+    def validate(self, body, results=None, counters=None):
+        """Returns (results, counters) tensors; counters are ADDED to."""
+        import torch
+
+        _check_body(body, self.ctx.device)
+        dev = body.device
+        if results is None:
+            results = torch.empty((max(self.n_obj, 1), 4), dtype=torch.int32, device=dev)
+        if counters is None:
+            counters = torch.zeros(NUM_COUNTERS, dtype=torch.int64, device=dev)
+        assert results.is_contiguous() and results.numel() * results.element_size() >= 16 * self.n_obj
+        assert counters.is_contiguous() and counters.numel() >= NUM_COUNTERS and counters.element_size() == 8
+        check(_lib.lib().oval_validate(self.ctx.handle, self._h, body.data_ptr(), body.numel(),
+                                       results.data_ptr(), counters.data_ptr()))
+        return results, counters
+
+    def read_unit(self, body, byte_offset: int) -> bytes:
+        out = (C.c_uint8 * UNIT)()
+        check(_lib.lib().oval_read_unit(self.ctx.handle, body.data_ptr(), byte_offset, out))
+        return bytes(out)
+
+
+def _check_body(body, device: int) -> None:
+    if not (body.is_cuda and body.dtype.itemsize == 1 and body.is_contiguous()):
+        raise OvalError("body must be a contiguous 1-byte-element CUDA tensor")
+    if body.device.index != device:
+        raise OvalError(f"body is on cuda:{body.device.index}, context on cuda:{device}")
+
+
+def results_to_numpy(results, n_obj: int) -> np.ndarray:
+    """(n_obj,4) int32 CUDA tensor -> structured RESULT_DTYPE array on the host."""
+    arr = results[:n_obj].cpu().numpy().view(np.uint32).reshape(-1, 4)
+    out = np.empty(n_obj, dtype=RESULT_DTYPE)
+    out["first_bad_fields"] = arr[:, 0]
+    out["first_bad_unit"] = arr[:, 1]
+    out["bad_units"] = arr[:, 2]
+    out["strict_first_bad_unit"] = arr[:, 3]
+    return out
+
+
+class Timer:
+    """HIP events on the context's stream (oval_timer)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        check(_lib.lib().oval_timer_create(ctx.handle, C.byref(self._h)))
+
+    def start(self):
+        check(_lib.lib().oval_timer_start(self.ctx.handle, self._h))
+
+    def stop(self):
+        check(_lib.lib().oval_timer_stop(self.ctx.handle, self._h))
+
+    def elapsed_ms(self) -> float:
+        ms = C.c_float()
+        check(_lib.lib().oval_timer_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.lib().oval_timer_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass

@@ -1,0 +1,129 @@
+"""Mirror of the reference's internal/pattern package, bound to the C++ host
+layer (oval_amd/csrc/oval_pattern.cpp) which drives the HIP kernels.
+
+Go functions that return `error` raise PatternError here, whose text is what
+err.Error() returns in the reference; `None`/normal return stands for nil.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import OvalError
+from .object import Object
+
+dataUnitSize = 256  # pattern.go:18
+_ERR_CAP = 8192
+
+
+class PatternError(Exception):
+    """A Go `error` value of internal/pattern."""
+
+
+def _b(s) -> bytes:
+    return s.encode("utf-8") if isinstance(s, str) else bytes(s)
+
+
+def _raise(rc: int, err) -> None:
+    if rc == 0:
+        return
+    text = err.value.decode("utf-8", "surrogateescape")
+    if rc < 0:
+        raise OvalError(text or _lib.last_error())
+    raise PatternError(text)
+
+
+def init(device: int = 0) -> None:
+    _lib.check(_lib.lib().oval_pattern_init(device))
+
+
+def shutdown() -> None:
+    _lib.lib().oval_pattern_shutdown()
+
+
+def set_clock(unix_micro: int) -> None:
+    """Pins time.Now().UnixMicro() (pattern.go:103-104); < 0 = wall clock."""
+    _lib.lib().oval_pattern_set_clock(unix_micro)
+
+
+def seed(s: int) -> None:
+    _lib.lib().oval_pattern_seed(s)
+
+
+def DecideSize(minSize: int, maxSize: int, y: float | None = None) -> int:
+    """pattern.go:22-71; `y` optionally supplies rand.Float64()."""
+    size = C.c_int64()
+    err = C.create_string_buffer(256)
+    if y is None:
+        rc = _lib.lib().oval_pattern_decide_size(minSize, maxSize, C.byref(size), err, 256)
+    else:
+        rc = _lib.lib().oval_pattern_decide_size_y(minSize, maxSize, y, C.byref(size), err, 256)
+    _raise(rc, err)
+    return size.value
+
+
+def Generate(dataSize: int, workerID: int, bucketName, obj: Object) -> bytes:
+    """pattern.go:73-92"""
+    b, k = _b(bucketName), _b(obj.Key)
+    out = np.empty(max(dataSize, 1), dtype=np.uint8)
+    err = C.create_string_buffer(_ERR_CAP)
+    rc = _lib.lib().oval_pattern_generate(dataSize, workerID, b, len(b), k, len(k), obj.WriteCount,
+                                          out.ctypes.data, err, _ERR_CAP)
+    _raise(rc, err)
+    return out[:dataSize].tobytes()
+
+
+def generateDataUnit(unitCount: int, workerID: int, bucketName, obj: Object) -> bytes:
+    """pattern.go:94-116"""
+    b, k = _b(bucketName), _b(obj.Key)
+    out = np.empty(dataUnitSize, dtype=np.uint8)
+    err = C.create_string_buffer(_ERR_CAP)
+    rc = _lib.lib().oval_pattern_generate_data_unit(unitCount, workerID, b, len(b), k, len(k), obj.WriteCount,
+                                                    out.ctypes.data, err, _ERR_CAP)
+    _raise(rc, err)
+    return out.tobytes()
+
+
+def Valid(workerID: int, expectedBucketName, obj: Object, reader) -> None:
+    """pattern.go:118-134; `reader` is bytes-like (the whole body the io.Reader
+    would deliver)."""
+    b, k = _b(expectedBucketName), _b(obj.Key)
+    body = np.frombuffer(_b(reader), dtype=np.uint8) if not isinstance(reader, np.ndarray) else reader
+    body = np.ascontiguousarray(body, dtype=np.uint8)
+    err = C.create_string_buffer(_ERR_CAP)
+    ptr = body.ctypes.data if body.size else None
+    rc = _lib.lib().oval_pattern_valid(workerID, b, len(b), k, len(k), obj.Size, obj.WriteCount, ptr, body.size,
+                                       err, _ERR_CAP)
+    _raise(rc, err)
+
+
+def validDataUnit(unitCount: int, workerID: int, expectedBucketName, obj: Object, data) -> None:
+    """pattern.go:136-180"""
+    b, k, d = _b(expectedBucketName), _b(obj.Key), _b(data)
+    if len(d) != dataUnitSize:
+        raise ValueError("a data unit is 256 bytes")
+    err = C.create_string_buffer(_ERR_CAP)
+    arr = np.frombuffer(d, dtype=np.uint8)
+    rc = _lib.lib().oval_pattern_valid_data_unit(unitCount, workerID, b, len(b), k, len(k), obj.WriteCount,
+                                                 arr.ctypes.data, err, _ERR_CAP)
+    _raise(rc, err)
+
+
+def hexDump(data) -> str:
+    d = _b(data)
+    cap = 80 * (len(d) // 16 + 2)
+    out = C.create_string_buffer(cap)
+    arr = np.frombuffer(d, dtype=np.uint8)
+    n = _lib.lib().oval_pattern_hex_dump(arr.ctypes.data if len(d) else None, len(d), out, cap)
+    return out.raw[:n].decode("latin-1")
+
+
+def dump(data) -> str:
+    """pattern.go:182-206"""
+    d = _b(data) if not isinstance(data, str) else data.encode("latin-1")
+    cap = len(d) + 1024
+    out = C.create_string_buffer(cap)
+    n = _lib.lib().oval_pattern_dump(d, len(d), out, cap)
+    return out.raw[:n].decode("latin-1")

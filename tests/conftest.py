@@ -1,0 +1,49 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu() -> bool:
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this process")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+
+    d = os.path.join(ROOT, "tests", "golden")
+    return {
+        "readme": json.load(open(os.path.join(d, "readme_unit.json"))),
+        "pattern_test": json.load(open(os.path.join(d, "pattern_test.json"))),
+    }

@@ -1,0 +1,98 @@
+"""CPU-only checks of the batch tables: key ranges, sharding by worker key
+range, synthetic batches, corruption plans (verified with the oracle)."""
+import numpy as np
+import pytest
+
+from oval_amd.batch import (WorkerSpace, apply_corruption_numpy, build_descs, decide_sizes, make_keys,
+                            plan_corruption, shard_workers, span_bytes, synthetic_batch)
+
+T0 = 1709558129112997
+
+
+def test_make_keys_matches_generate_key(oracle):
+    ids = np.array([0, 1, 255, (2 << 24) + 0xE2, (7 << 32) + (200 << 24) + 0xFFFFFF, (1 << 40) - 1], dtype=np.uint64)
+    keys = make_keys(ids)
+    for i, oid in enumerate(ids):
+        assert keys[i].tobytes().decode() == oracle.generate_key(int(oid))
+    with pytest.raises(ValueError):
+        make_keys(np.array([1 << 40], dtype=np.uint64))
+
+
+def test_worker_space_matches_readme_key_ranges():
+    # README.md:71-74: 4 workers x 256 objects, runner 0
+    sp = WorkerSpace(num_obj=1024, num_worker=4, runner_id=0, start_worker_id=0x614)
+    for w, (head, tail) in enumerate([("ov0000000000", "ov00000000ff"), ("ov0001000000", "ov00010000ff"),
+                                      ("ov0002000000", "ov00020000ff"), ("ov0003000000", "ov00030000ff")]):
+        keys = make_keys(sp.obj_ids([w]))
+        assert keys[0].tobytes().decode() == head and keys[-1].tobytes().decode() == tail
+    assert list(np.unique(sp.stamped_worker_ids(range(4)))) == [0x614, 0x615, 0x616, 0x617]
+    sp2 = WorkerSpace(1024, 4, start_worker_id=0xFFFE)
+    assert list(sp2.stamped_worker_ids(range(4))[::256]) == [0xFFFE, 0xFFFF, 0, 1]     # runner.go:113 wraps
+
+
+@pytest.mark.parametrize("nw,ws", [(64, 8), (64, 1), (7, 2), (255, 8), (4, 8), (3, 4)])
+def test_shard_workers_partitions(nw, ws):
+    got = [w for r in range(ws) for w in shard_workers(nw, ws, r)]
+    assert got == list(range(nw))
+    sizes = [len(shard_workers(nw, ws, r)) for r in range(ws)]
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_synthetic_batch_is_shard_invariant():
+    sp = WorkerSpace(num_obj=4096, num_worker=8, start_worker_id=77)
+    whole = synthetic_batch(sp, range(8), "test-bucket", 4096, 16384, seed=5, unix_micro=T0)
+    parts = [synthetic_batch(sp, shard_workers(8, 4, r), "test-bucket", 4096, 16384, seed=5, unix_micro=T0)
+             for r in range(4)]
+    cat = np.concatenate(parts)
+    for f in ("key", "write_count", "worker_id", "n_units", "bucket", "unix_micro"):
+        assert (cat[f] == whole[f]).all(), f
+    assert all(p["body_offset"][0] == 0 for p in parts)       # each rank's buffer starts at 0
+    assert whole["n_units"].min() >= 16 and whole["n_units"].max() <= 64
+    assert 1 <= whole["write_count"].min() and whole["write_count"].max() <= 1000
+
+
+def test_decide_sizes_matches_scalar(oracle):
+    rng = np.random.default_rng(0)
+    y = rng.random(5000)
+    for lo, hi in ((4096, 16384), (4096, 1 << 20), (256, 256)):
+        v = decide_sizes(y, lo, hi)
+        s = np.array([oracle.decide_size(lo, hi, float(t)) for t in y])
+        assert (np.abs(v - s) <= 256).all() and (v == s).mean() > 0.999
+        assert v.min() >= lo and v.max() <= hi
+
+
+def test_build_descs_layout_and_gaps(oracle):
+    d = build_descs("test-long-long-long-bucket", ["a", "bb", "ccc"], [1, 2, 3], 9, T0, [512, 0, 1024], gap_bytes=256)
+    assert list(d["body_offset"]) == [0, 768, 1024] and list(d["n_units"]) == [2, 0, 4]
+    assert bytes(d[0]["bucket"]) == b"test-long-long-l" and d[0]["bucket_len"] == 16
+    assert span_bytes(d) == 2048
+    body = np.full(2048, 0xEE, dtype=np.uint8)
+    oracle.fill_batch(d.view(oracle.DESC_DTYPE), body)
+    assert (body[512:768] == 0xEE).all() and (body[768:1024] == 0xEE).all()     # gaps untouched
+    assert body[0:16].tobytes() == b"test-long-long-l"
+
+
+def test_corruption_plan_agrees_with_oracle(oracle):
+    sp = WorkerSpace(num_obj=512, num_worker=4, start_worker_id=9)
+    d = synthetic_batch(sp, range(4), "test-bucket", 4096, 16384, seed=1, unix_micro=T0)
+    body = np.zeros(span_bytes(d), dtype=np.uint8)
+    D = d.view(oracle.DESC_DTYPE)
+    oracle.fill_batch(D, body)
+    plan = plan_corruption(d, fraction=2e-3, seed=3)
+    assert len(plan.flip_byte) + len(plan.stale_obj) >= 30
+    apply_corruption_numpy(body, d, plan)
+    res, cnt = oracle.validate_batch(D, body)
+    bad = np.flatnonzero(res["first_bad_unit"] != oracle.NO_BAD)
+    # every stale-generation unit is reference-visible (write count), flips only in bytes [0,40)
+    assert set(plan.stale_obj) <= set(bad)
+    vis = plan._flip_obj[(plan.flip_byte % 256) < 40]
+    assert set(bad) == set(plan.stale_obj) | set(vis)
+    # strict sees everything except flips inside the time bytes
+    strict_bad = np.flatnonzero(res["strict_first_bad_unit"] != oracle.NO_BAD)
+    hidden = (plan.flip_byte % 256 >= 40) & (plan.flip_byte % 256 < 48)
+    assert set(strict_bad) == set(plan.stale_obj) | set(plan._flip_obj[~hidden])
+    # first bad unit of a stale-only object is its lowest stale unit, fields = write count
+    for o in set(plan.stale_obj) - set(plan._flip_obj):
+        assert res["first_bad_unit"][o] == plan.stale_unit[plan.stale_obj == o].min()
+        assert res["first_bad_fields"][o] == 4
+    assert cnt[1] == len(bad) and cnt[3] == res["bad_units"].sum()

@@ -1,0 +1,64 @@
+"""world_size-2 rehearsal of the multi-GPU path on CPU (gloo): objects shard by
+worker key range, every rank validates only its own shard, and one all-reduce
+of the counter vector gives every rank the batch totals.  The per-shard compute
+is done by the oracle here (there is no GPU in this test)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oval_amd.batch import WorkerSpace, apply_corruption_numpy, plan_corruption, span_bytes, synthetic_batch
+from oval_amd.dist import all_reduce_counters, shard_batch
+
+T0 = 1709558129112997
+SPACE = dict(num_obj=768, num_worker=6, runner_id=1, start_worker_id=0xFFFD)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_counters(rank, world):
+    from oracle import oracle as O
+
+    sp = WorkerSpace(**SPACE)
+    d = shard_batch(sp, world, rank, "test-bucket", 4096, 16384, seed=7, unix_micro=T0)
+    body = np.zeros(span_bytes(d), dtype=np.uint8)
+    O.fill_batch(d.view(O.DESC_DTYPE), body)
+    apply_corruption_numpy(body, d, plan_corruption(d, 1e-3, seed=100 + rank))
+    _, cnt = O.validate_batch(d.view(O.DESC_DTYPE), body)
+    return d, cnt
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d, cnt = _shard_counters(rank, world)
+    t = torch.from_numpy(cnt.astype(np.int64))
+    all_reduce_counters(t)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), t.numpy())
+    np.save(os.path.join(out_dir, f"k{rank}.npy"), d["key"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sum_to_the_whole(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"r{r}.npy") for r in range(world)]
+    assert (got[0] == got[1]).all()                       # every rank holds the totals
+    expect = sum(_shard_counters(r, world)[1].astype(np.int64) for r in range(world))
+    assert (got[0] == expect).all()
+    assert got[0][0] == SPACE["num_obj"] and got[0][1] > 0 and got[0][3] >= got[0][1]
+    # the shards are disjoint and cover every key of the run
+    keys = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])
+    whole = synthetic_batch(WorkerSpace(**SPACE), range(SPACE["num_worker"]), "test-bucket", 4096, 16384, 7, T0)
+    assert (keys == whole["key"]).all() and len(np.unique(keys, axis=0)) == SPACE["num_obj"]
