@@ -35,12 +35,14 @@ WORKLOADS = {
 }
 
 
-def build_batch(name, rank, n_obj_override, seed):
+def build_batch(name, rank, n_obj_override, seed, size_override=None):
     from oval_amd.batch import WorkerSpace, synthetic_batch
 
     n_obj, n_worker, lo, hi, _ = WORKLOADS[name]
     if n_obj_override:
         n_obj = n_obj_override
+    if size_override:
+        lo, hi = size_override
     n_worker = min(n_worker, n_obj)
     n_obj -= n_obj % n_worker
     space = WorkerSpace(num_obj=n_obj, num_worker=n_worker, runner_id=rank, start_worker_id=0x561B)
@@ -99,9 +101,10 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--objects", type=int, default=0, help="objects per GPU (default: the workload's)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--sizes", default="", help="override object sizes, e.g. 65536-65536 (bytes, multiples of 256)")
     args = ap.parse_args()
 
     import torch
@@ -130,7 +133,8 @@ def main():
     ctx = engine.Context(local, stream.cuda_stream)
     ctx.set_tuning(args.blocks_per_cu, args.variant)
 
-    descs = build_batch(args.workload, rank, args.objects, args.seed)
+    size_override = tuple(int(x) for x in args.sizes.split("-")) if args.sizes else None
+    descs = build_batch(args.workload, rank, args.objects, args.seed, size_override)
     n_obj, units = len(descs), int(descs["n_units"].sum())
     nbytes = span_bytes(descs)
     layout = engine.Layout(ctx, descs)
@@ -196,7 +200,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][4]}", "objects_per_gpu": n_obj,
                        "units_per_gpu": units, "bytes_per_gpu": nbytes, "sharding": "worker key range (process ID = rank)",
-                       "blocks_per_cu": args.blocks_per_cu or 8, "variant": args.variant},
+                       "blocks_per_cu": args.blocks_per_cu or "auto", "variant": args.variant if args.variant >= 0 else "auto"},
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -214,7 +214,10 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs_host, uin
                              oval_obj_result* results_host, uint64_t* counters_host);
 
 /* ---- kernel launch tuning (benchmarks only) ------------------------------
- * blocks_per_cu <= 0 restores the default. */
+ * By default the library picks the kernel family and grid per launch from the
+ * batch shape.  blocks_per_cu > 0 and/or variant >= 0 pin them (variant bit 0:
+ * XCD-contiguous tile order, bit 2: group-walk kernels, bits 4-5: unroll);
+ * blocks_per_cu <= 0 / variant < 0 restore the automatic choice. */
 int oval_ctx_set_tuning(oval_ctx* ctx, int blocks_per_cu, int variant);
 
 /* ---- timing --------------------------------------------------------------

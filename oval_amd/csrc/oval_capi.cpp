@@ -36,8 +36,8 @@ struct oval_ctx {
     bool        own_stream  = false;
     hipStream_t copy_stream = nullptr;   // second stream for overlapped host copies
     int         n_cu        = 256;
-    int         blocks_per_cu = 8;
-    int         variant     = 0;
+    int         blocks_per_cu = 0;     // 0: chosen per kernel and batch shape
+    int         variant     = -1;      // -1: chosen per kernel and batch shape
 };
 
 struct oval_layout {
@@ -92,11 +92,21 @@ oval::LayoutView view_of(const oval_layout* l)
     return v;
 }
 
-oval::LaunchCfg cfg_of(const oval_ctx* c)
+// Launch shape.  Measured on MI355X (tools/sweep2.sh): the group-walk kernels
+// (variant 4) are fastest for validation at 4 workgroups per CU whatever the
+// object size, and for filling small objects at 2 per CU; the wave-walk fill
+// (variant 0) wins once objects average 32 KiB or more.  An explicit
+// oval_ctx_set_tuning() overrides either choice.
+oval::LaunchCfg cfg_of(const oval_ctx* c, const oval_layout* l, bool is_fill)
 {
+    const uint64_t mean_units = l->n_obj ? l->total_units / l->n_obj : 0;
+    int variant = c->variant;
+    int bpc = c->blocks_per_cu;
+    if (variant < 0) variant = (is_fill && mean_units >= 128) ? 0 : 4;
+    if (bpc <= 0) bpc = is_fill ? ((variant & 4) ? 2 : 4) : 4;
     oval::LaunchCfg k;
-    k.grid_blocks = c->n_cu * c->blocks_per_cu;
-    k.variant = c->variant;
+    k.grid_blocks = c->n_cu * bpc;
+    k.variant = variant;
     return k;
 }
 
@@ -195,8 +205,8 @@ int oval_ctx_stream(oval_ctx* ctx, void** stream_out)
 int oval_ctx_set_tuning(oval_ctx* ctx, int blocks_per_cu, int variant)
 {
     if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
-    ctx->blocks_per_cu = blocks_per_cu > 0 ? (blocks_per_cu > 64 ? 64 : blocks_per_cu) : 8;
-    ctx->variant = variant < 0 ? 0 : variant;
+    ctx->blocks_per_cu = blocks_per_cu > 0 ? (blocks_per_cu > 64 ? 64 : blocks_per_cu) : 0;
+    ctx->variant = variant < 0 ? -1 : variant;
     return OVAL_OK;
 }
 
@@ -418,7 +428,7 @@ int oval_fill(oval_ctx* ctx, const oval_layout* l, void* body_dev, uint64_t body
     if (l->no_fill)
         return fail(OVAL_E_FIELD, "the layout holds an object whose names do not format to 28 bytes; "
                                   "the reference's Generate fails for it (pattern.go:87-89)");
-    HIP_TRY(oval::launch_fill(ctx->stream, cfg_of(ctx), view_of(l), body_dev, 0, tiles_of(l)));
+    HIP_TRY(oval::launch_fill(ctx->stream, cfg_of(ctx, l, true), view_of(l), body_dev, 0, tiles_of(l)));
     return OVAL_OK;
 }
 
@@ -432,7 +442,7 @@ int oval_validate(oval_ctx* ctx, const oval_layout* l, const void* body_dev, uin
     if (((uintptr_t)counters_dev) % 8) return fail(OVAL_E_INVALID, "counters_dev is not 8-byte aligned");
     const oval::LayoutView v = view_of(l);
     HIP_TRY(oval::launch_init_results(ctx->stream, v, results_dev, (unsigned long long*)counters_dev));
-    HIP_TRY(oval::launch_validate(ctx->stream, cfg_of(ctx), v, body_dev, 0, tiles_of(l), results_dev,
+    HIP_TRY(oval::launch_validate(ctx->stream, cfg_of(ctx, l, false), v, body_dev, 0, tiles_of(l), results_dev,
                                   (unsigned long long*)counters_dev));
     return OVAL_OK;
 }
@@ -477,7 +487,7 @@ int oval_fill_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_o
     uint32_t k = 0;
     for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles, ++k) {
         const uint32_t t1 = t0 + kSliceTiles < n_tiles ? t0 + kSliceTiles : n_tiles;
-        e = oval::launch_fill(ctx->stream, cfg_of(ctx), v, dev, t0, t1);
+        e = oval::launch_fill(ctx->stream, cfg_of(ctx, l, true), v, dev, t0, t1);
         if (e == hipSuccess) e = hipEventRecord(ev[k & 1], ctx->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ev[k & 1], 0);
         const uint64_t b0 = (uint64_t)t0 * kTileBytes;
@@ -534,7 +544,7 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
                                ctx->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(ev, ctx->copy_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
-        if (e == hipSuccess) e = oval::launch_validate(ctx->stream, cfg_of(ctx), v, dev, t0, t1, res_dev, cnt_dev);
+        if (e == hipSuccess) e = oval::launch_validate(ctx->stream, cfg_of(ctx, l, false), v, dev, t0, t1, res_dev, cnt_dev);
     }
     if (e == hipSuccess && n_obj)
         e = hipMemcpyAsync(results_host, res_dev, n_obj * sizeof(oval_obj_result), hipMemcpyDeviceToHost, ctx->stream);

@@ -386,6 +386,325 @@ __global__ __launch_bounds__(256) void validate_kernel(const u32x4* __restrict__
     }
 }
 
+// ===========================================================================
+// Wave-walk kernels.
+//
+// One wavefront instruction covers four CONSECUTIVE units (1 KiB contiguous),
+// a wavefront pass covers one 64 KiB tile, and the walk over objects is done
+// once per wavefront on the scalar unit: descriptors are fetched with scalar
+// loads (constant address space), so waiting for one never drains the vector
+// memory queue that holds the body's stores or prefetched loads.
+// ===========================================================================
+typedef const __attribute__((address_space(4))) u32x4* sdesc_ptr;
+
+// Wave-uniform view of the current object.
+struct WObj {
+    uint32_t o, start, end, lf, ubias;
+    u32x4 d0, d1, d2;          // bytes [0,48) of the descriptor = header template
+};
+
+// A descriptor fetched ahead of need (one s_load_dwordx16), not yet decoded.
+struct WRaw {
+    uint32_t o;
+    u32x4 d0, d1, d2, d3;
+};
+
+// n_obj >= 1.  The load is unconditional (index clamped to the last object) so
+// that nothing touches the destination registers before the values are needed:
+// the wait for it then sits at the next object switch, not here.
+__device__ __forceinline__ void w_fetch(sdesc_ptr descs, uint32_t n_obj, uint32_t o, WRaw& r)
+{
+    const uint32_t oc = o < n_obj ? o : n_obj - 1u;
+    r.o = o < n_obj ? o : n_obj;
+    r.d0 = descs[4u * oc];
+    r.d1 = descs[4u * oc + 1u];
+    r.d2 = descs[4u * oc + 2u];
+    r.d3 = descs[4u * oc + 3u];
+}
+
+__device__ __forceinline__ void w_activate(const WRaw& r, uint32_t n_obj, WObj& w)
+{
+    // Every fetched register counts as read here, so none of them is handed
+    // out as a temporary (and waited for) while the fetch is still in flight.
+    asm volatile("" ::"s"(r.d0), "s"(r.d1), "s"(r.d2), "s"(r.d3));
+    w.o = r.o;
+    w.d0 = r.d0; w.d1 = r.d1; w.d2 = r.d2;
+    if (r.o < n_obj) {
+        w.start = (r.d3.x >> 8) | (r.d3.y << 24);              // body_offset / 256
+        w.end = w.start + r.d3.z;
+        w.lf = r.d3.w;
+        w.ubias = r.d2.x - w.start;                            // first_unit - start
+    } else {
+        w.start = kNone; w.end = kNone; w.lf = 0; w.ubias = 0;
+    }
+}
+
+// Make object `o` current and start fetching its successor.
+__device__ __forceinline__ void w_enter(sdesc_ptr descs, uint32_t n_obj, uint32_t o, WObj& w, WRaw& next)
+{
+    WRaw r;
+    w_fetch(descs, n_obj, o, r);
+    w_fetch(descs, n_obj, o + 1u, next);
+    w_activate(r, n_obj, w);
+}
+
+// Stepping to the successor is done in two halves by the kernels: w_activate
+// + rebuilding the lane template (which reads the fetched registers), then,
+// behind a scheduling barrier, w_fetch of the one after it.  Issued earlier,
+// the fetch would need registers of its own and be copied (and waited for)
+// on the spot.
+// This lane's expected 16 bytes for unit index 0 of the walk (lane 2's .x gets
+// + (g << 8) per unit).
+__device__ __forceinline__ u32x4 w_lane_template(const WObj& w, int j, const u32x4& cpat)
+{
+    u32x4 t = cpat;
+    if (j == 0) t = w.d0;
+    if (j == 1) t = w.d1;
+    if (j == 2) { t = w.d2; t.x = w.ubias << 8; }
+    return t;
+}
+
+__device__ __forceinline__ uint32_t w_lane_force(const WObj& w, int j)
+{
+    return (j < 3) ? ((w.lf >> 16) & (1u << j)) : 0u;
+}
+
+__device__ __forceinline__ uint32_t wave_tile_begin(uint32_t tile_begin, uint32_t tile_end, int variant,
+                                                    uint32_t& end, uint32_t& stride)
+{
+    TileIter it = make_tile_iter(tile_begin, tile_end, variant);
+    end = __builtin_amdgcn_readfirstlane(it.end);
+    stride = __builtin_amdgcn_readfirstlane(it.stride);
+    return __builtin_amdgcn_readfirstlane(it.tile);
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void fill_wave_kernel(sdesc_ptr descs, const uint32_t* __restrict__ tile_first,
+                                                        uint32_t n_obj, u32x4* __restrict__ body,
+                                                        uint32_t tile_begin, uint32_t tile_end, int variant)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const uint32_t grp = (uint32_t)lane >> 4;
+    const uint32_t gmul = (j == 2) ? 256u : 0u;
+    const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
+                        filler_dword(4u * j + 3u)};
+    uint32_t t_end, t_stride;
+    for (uint32_t tile = wave_tile_begin(tile_begin, tile_end, variant, t_end, t_stride); tile < t_end;
+         tile += t_stride) {
+        const uint32_t g_tile = tile * (kUnitsPerChunk * kChunksPerTile);
+        WObj w;
+        WRaw next;
+        w_enter(descs, n_obj, __builtin_amdgcn_readfirstlane(tile_first[tile * kChunksPerTile]), w, next);
+        u32x4 tmpl = w_lane_template(w, j, cpat);
+        u32x4* const tile_ptr = body + (size_t)g_tile * 16u + (uint32_t)lane;
+#pragma unroll UNROLL
+        for (uint32_t k = 0; k < kUnitsPerChunk; ++k) {
+            const uint32_t g4 = g_tile + 4u * k;
+            const uint32_t g = g4 + grp;
+            if (g4 >= w.start && g4 + 4u <= w.end) {            // all four units inside the object
+                u32x4 e = tmpl;
+                e.x += g * gmul;
+                tile_ptr[k * 64u] = e;
+            } else {
+                for (;;) {
+                    if (g >= w.start && g < w.end) {
+                        u32x4 e = tmpl;
+                        e.x += g * gmul;
+                        tile_ptr[k * 64u] = e;
+                    }
+                    if (w.end >= g4 + 4u) break;                 // kNone for "no more objects"
+                    w_activate(next, n_obj, w);
+                    tmpl = w_lane_template(w, j, cpat);
+                    __builtin_amdgcn_sched_barrier(0);
+                    w_fetch(descs, n_obj, w.o + 1u, next);
+                }
+            }
+        }
+    }
+}
+
+// Running outcome for the current object, wave-uniform.
+struct WRun {
+    uint32_t first, mask, cnt, sfirst;
+};
+
+struct WTotals {
+    uint32_t units, bucket, key, wc, off, wid, strict;
+};
+
+__device__ __forceinline__ void w_flush(oval_obj_result* __restrict__ results,
+                                        unsigned long long* __restrict__ counters, const WObj& w, WRun& r,
+                                        int lane)
+{
+    if (r.cnt != 0u || r.sfirst != kNone) {
+        if (lane == 0) {
+            oval_obj_result* R = results + w.o;
+            if (r.cnt != 0u) {
+                const unsigned long long key =
+                    ((unsigned long long)(r.first + w.ubias) << 32) | (unsigned long long)r.mask;
+                atomicMin(reinterpret_cast<unsigned long long*>(R), key);
+                const uint32_t old = atomicAdd(&R->bad_units, r.cnt);
+                if (old == 0u && counters) atomicAdd(&counters[OVAL_CNT_OBJECTS_BAD], 1ull);
+            }
+            atomicMin(&R->strict_first_bad_unit, r.sfirst + w.ubias);
+        }
+        r.first = kNone; r.mask = 0; r.cnt = 0; r.sfirst = kNone;
+    }
+}
+
+// Exact verdict for the lanes flagged `bad` in one wavefront instruction (four
+// units, all inside object w): per-field masks, then a ballot over the
+// wavefront gives the lowest bad unit and the number of bad units.
+__device__ __forceinline__ void w_handle_bad(const u32x4& v, uint32_t ex, const u32x4& tmpl, uint32_t lf,
+                                          uint32_t force, bool bad, int j, uint32_t g4, WRun& r, WTotals& t)
+{
+    uint32_t fm = 0;
+    if (bad) {
+        ObjState st;
+        st.tmpl = tmpl; st.lf = lf; st.force = force;
+        st.o = 0; st.start = 0; st.end = 0; st.ubias = 0;
+        fm = lane_field_mask(v, ex, st, j);
+    }
+    fm |= __shfl_xor(fm, 1);
+    fm |= __shfl_xor(fm, 2);
+    fm |= __shfl_xor(fm, 4);
+    fm |= __shfl_xor(fm, 8);                                    // the unit's mask in all 16 lanes of its group
+    const uint32_t ref = fm & OVAL_REF_FIELDS;
+    const unsigned long long refb = __ballot(ref != 0u);
+    const unsigned long long anyb = __ballot(fm != 0u);
+    if (refb) {
+        const uint32_t first_lane = (uint32_t)__builtin_ctzll(refb);
+        if (r.cnt == 0u) {
+            r.first = g4 + (first_lane >> 4);
+            r.mask = (uint32_t)__builtin_amdgcn_readlane((int)ref, (int)first_lane);
+        }
+        const uint32_t n = (uint32_t)__builtin_popcountll(refb) >> 4;
+        r.cnt += n;
+        t.units += n;
+        t.bucket += (uint32_t)__builtin_popcountll(__ballot((ref & OVAL_BAD_BUCKET) != 0u)) >> 4;
+        t.key += (uint32_t)__builtin_popcountll(__ballot((ref & OVAL_BAD_KEY) != 0u)) >> 4;
+        t.wc += (uint32_t)__builtin_popcountll(__ballot((ref & OVAL_BAD_WRITECNT) != 0u)) >> 4;
+        t.off += (uint32_t)__builtin_popcountll(__ballot((ref & OVAL_BAD_OFFSET) != 0u)) >> 4;
+        t.wid += (uint32_t)__builtin_popcountll(__ballot((ref & OVAL_BAD_WORKER) != 0u)) >> 4;
+    }
+    if (anyb) {
+        if (r.sfirst == kNone) r.sfirst = g4 + ((uint32_t)__builtin_ctzll(anyb) >> 4);
+        t.strict += (uint32_t)__builtin_popcountll(anyb) >> 4;
+    }
+}
+
+__device__ __forceinline__ uint32_t w_diff(const u32x4& v, uint32_t ex, const u32x4& tmpl, uint32_t zwmask)
+{
+    return (v.x ^ ex) | (v.y ^ tmpl.y) | (((v.z ^ tmpl.z) | (v.w ^ tmpl.w)) & zwmask);
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void validate_wave_kernel(sdesc_ptr descs,
+                                                            const uint32_t* __restrict__ tile_first,
+                                                            uint32_t n_obj, uint32_t limit_units,
+                                                            const u32x4* __restrict__ body,
+                                                            uint32_t tile_begin, uint32_t tile_end,
+                                                            oval_obj_result* __restrict__ results,
+                                                            unsigned long long* __restrict__ counters,
+                                                            int variant)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const uint32_t grp = (uint32_t)lane >> 4;
+    const uint32_t gmul = (j == 2) ? 256u : 0u;
+    const uint32_t zwmask = (j == 2) ? 0u : 0xFFFFFFFFu;       // pattern.go:172 "Skip the unix time area."
+    const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
+                        filler_dword(4u * j + 3u)};
+    WTotals tot = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t t_end, t_stride;
+    for (uint32_t tile = wave_tile_begin(tile_begin, tile_end, variant, t_end, t_stride); tile < t_end;
+         tile += t_stride) {
+        const uint32_t g_tile = tile * (kUnitsPerChunk * kChunksPerTile);
+        WObj w;
+        WRaw next;
+        w_enter(descs, n_obj, __builtin_amdgcn_readfirstlane(tile_first[tile * kChunksPerTile]), w, next);
+        u32x4 tmpl = w_lane_template(w, j, cpat);
+        uint32_t force = w_lane_force(w, j);
+        WRun run = {kNone, 0, 0, kNone};
+        const u32x4* const tile_ptr = body + (size_t)g_tile * 16u + (uint32_t)lane;
+
+        for (uint32_t kb = 0; kb < kUnitsPerChunk; kb += UNROLL) {
+            bool careful = (run.cnt != 0u) || (run.sfirst != kNone);
+            const uint32_t o_batch = w.o;
+            if (!careful) {
+                // pass 1: stream the batch; no side effects until it is known to be clean
+                u32x4 v[UNROLL];
+#pragma unroll
+                for (int i = 0; i < UNROLL; ++i) {
+                    v[i] = (u32x4){0u, 0u, 0u, 0u};
+                    if (g_tile + 4u * (kb + i) + grp < limit_units)
+                        v[i] = __builtin_nontemporal_load(tile_ptr + (kb + i) * 64u);
+                }
+                uint32_t anybad = 0;
+#pragma unroll
+                for (int i = 0; i < UNROLL; ++i) {
+                    const uint32_t g4 = g_tile + 4u * (kb + i);
+                    const uint32_t g = g4 + grp;
+                    if (g4 >= w.start && g4 + 4u <= w.end) {
+                        anybad |= w_diff(v[i], tmpl.x + g * gmul, tmpl, zwmask) | force;
+                    } else {
+                        for (;;) {
+                            if (g >= w.start && g < w.end)
+                                anybad |= w_diff(v[i], tmpl.x + g * gmul, tmpl, zwmask) | force;
+                            if (w.end >= g4 + 4u) break;
+                            w_activate(next, n_obj, w);
+                            tmpl = w_lane_template(w, j, cpat);
+                            force = w_lane_force(w, j);
+                            __builtin_amdgcn_sched_barrier(0);
+                            w_fetch(descs, n_obj, w.o + 1u, next);
+                        }
+                    }
+                }
+                if (__any(anybad != 0u)) {
+                    careful = true;                             // rewind to the batch's first object
+                    w_enter(descs, n_obj, o_batch, w, next);
+                    tmpl = w_lane_template(w, j, cpat);
+                    force = w_lane_force(w, j);
+                }
+            }
+            if (careful) {
+                // pass 2: the same units one instruction at a time, with the exact verdicts
+#pragma unroll 1
+                for (int i = 0; i < UNROLL; ++i) {
+                    const uint32_t g4 = g_tile + 4u * (kb + i);
+                    const uint32_t g = g4 + grp;
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (g < limit_units) v = __builtin_nontemporal_load(tile_ptr + (kb + i) * 64u);
+                    for (;;) {
+                        const uint32_t ex = tmpl.x + g * gmul;
+                        const bool bad = (g >= w.start && g < w.end) &&
+                                         ((w_diff(v, ex, tmpl, zwmask) | force) != 0u);
+                        if (__any(bad)) w_handle_bad(v, ex, tmpl, w.lf, force, bad, j, g4, run, tot);
+                        if (w.end >= g4 + 4u) break;
+                        w_flush(results, counters, w, run, lane);
+                        w_activate(next, n_obj, w);
+                        tmpl = w_lane_template(w, j, cpat);
+                        force = w_lane_force(w, j);
+                        __builtin_amdgcn_sched_barrier(0);
+                        w_fetch(descs, n_obj, w.o + 1u, next);
+                    }
+                }
+            }
+        }
+        if (w.o < n_obj) w_flush(results, counters, w, run, lane);
+    }
+    if (counters && tot.strict != 0u && lane == 0) {
+        if (tot.units) atomicAdd(&counters[OVAL_CNT_UNITS_BAD], (unsigned long long)tot.units);
+        if (tot.bucket) atomicAdd(&counters[OVAL_CNT_BAD_BUCKET], (unsigned long long)tot.bucket);
+        if (tot.key) atomicAdd(&counters[OVAL_CNT_BAD_KEY], (unsigned long long)tot.key);
+        if (tot.wc) atomicAdd(&counters[OVAL_CNT_BAD_WRITECNT], (unsigned long long)tot.wc);
+        if (tot.off) atomicAdd(&counters[OVAL_CNT_BAD_OFFSET], (unsigned long long)tot.off);
+        if (tot.wid) atomicAdd(&counters[OVAL_CNT_BAD_WORKER], (unsigned long long)tot.wid);
+        atomicAdd(&counters[OVAL_CNT_STRICT_UNITS_BAD], (unsigned long long)tot.strict);
+    }
+}
+
 // results[i] = {none, none, 0, none}; counters += objects/units checked
 __global__ __launch_bounds__(256) void init_results_kernel(u32x4* __restrict__ results, uint32_t n_obj,
                                                            unsigned long long* __restrict__ counters,
@@ -430,6 +749,19 @@ hipError_t launch_fill(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv
     if (tile_end <= tile_begin) return hipSuccess;
     const int grid = clamp_grid(cfg.grid_blocks, tile_end - tile_begin);
     const int variant = cfg.variant & 1;
+    if (!(cfg.variant & 4)) {
+        sdesc_ptr sd = (sdesc_ptr)lv.descs;
+        u32x4* b = static_cast<u32x4*>(body);
+#define OVAL_LAUNCH_FILL(U) fill_wave_kernel<U><<<grid, kBlockThreads, 0, s>>>(sd, lv.chunk_first, lv.n_obj, b, tile_begin, tile_end, variant)
+        switch ((cfg.variant >> 4) & 3) {
+        case 1: OVAL_LAUNCH_FILL(2); break;
+        case 2: OVAL_LAUNCH_FILL(8); break;
+        case 3: OVAL_LAUNCH_FILL(16); break;
+        default: OVAL_LAUNCH_FILL(4); break;
+        }
+#undef OVAL_LAUNCH_FILL
+        return hipGetLastError();
+    }
     if (cfg.variant & 2)
         fill_kernel<8><<<grid, kBlockThreads, 0, s>>>(static_cast<const u32x4*>(lv.descs), lv.chunk_first,
                                                       lv.n_obj, lv.n_chunks, static_cast<u32x4*>(body),
@@ -459,6 +791,19 @@ hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView
     if (tile_end <= tile_begin) return hipSuccess;
     const int grid = clamp_grid(cfg.grid_blocks, tile_end - tile_begin);
     const int variant = cfg.variant & 1;
+    if (!(cfg.variant & 4)) {
+        sdesc_ptr sd = (sdesc_ptr)lv.descs;
+        const u32x4* b = static_cast<const u32x4*>(body);
+#define OVAL_LAUNCH_VAL(U) validate_wave_kernel<U><<<grid, kBlockThreads, 0, s>>>(sd, lv.chunk_first, lv.n_obj, lv.span_units, b, tile_begin, tile_end, results, counters, variant)
+        switch ((cfg.variant >> 4) & 3) {
+        case 1: OVAL_LAUNCH_VAL(2); break;
+        case 2: OVAL_LAUNCH_VAL(4); break;
+        case 3: OVAL_LAUNCH_VAL(16); break;
+        default: OVAL_LAUNCH_VAL(8); break;
+        }
+#undef OVAL_LAUNCH_VAL
+        return hipGetLastError();
+    }
     if (cfg.variant & 2)
         validate_kernel<8><<<grid, kBlockThreads, 0, s>>>(
             static_cast<const u32x4*>(lv.descs), lv.chunk_first, lv.n_obj, lv.n_chunks, lv.span_units,
