@@ -185,7 +185,12 @@ def main():
         value = 512.0 * units_all / (wall / args.steps) / 1e9
         fill_gbs = 256.0 * units / (fill_ms / 1e3) / 1e9
         val_gbs = 256.0 * units / (val_ms / 1e3) / 1e9
-        dom, dom_ms, dom_gbs = ("validate_kernel", val_ms, val_gbs) if val_ms >= fill_ms else ("fill_kernel", fill_ms, fill_gbs)
+        # kernel names as rocprofv3 reports them; the library picks the fill family by mean object size
+        auto = args.variant < 0
+        wave = (units // max(n_obj, 1) >= 128) if auto else not (args.variant & 4)
+        fill_name = "fill_wave_kernel<4>" if wave else "fill_kernel<4>"
+        val_name = "validate_kernel<4>" if auto or (args.variant & 4) else "validate_wave_kernel<8>"
+        dom, dom_ms, dom_gbs = (val_name, val_ms, val_gbs) if val_ms >= fill_ms else (fill_name, fill_ms, fill_gbs)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
