@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Host-inclusive rate of the pattern path: bodies start (validate) and end
+(fill) in host memory, as they do behind an S3 socket.  Uses pinned buffers
+from oval_pinned_alloc and the one-shot C-ABI calls, which slice the batch and
+overlap PCIe copies with the kernels on a second stream.
+
+  python tools/host_inclusive.py [objects] > profiles/r01_host_inclusive.txt
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from oval_amd import _lib, engine  # noqa: E402
+from oval_amd.batch import WorkerSpace, span_bytes, synthetic_batch  # noqa: E402
+
+T0 = 1709558129112997
+
+
+def main():
+    n_obj = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+    n_obj -= n_obj % 64
+    descs = synthetic_batch(WorkerSpace(n_obj, 64, start_worker_id=0x561B), range(64), "test-bucket",
+                            4096, 16384, seed=1, unix_micro=T0)
+    nbytes = span_bytes(descs)
+    units = int(descs["n_units"].sum())
+    ctx = engine.Context(0)
+    L = _lib.lib()
+    rows = []
+    for kind in ("pinned", "pageable"):
+        if kind == "pinned":
+            p = C.c_void_p()
+            _lib.check(L.oval_pinned_alloc(ctx.handle, nbytes, C.byref(p)))
+            host = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+        else:
+            host = np.zeros(nbytes, dtype=np.uint8)
+        for rep in range(3):
+            t = time.perf_counter()
+            ctx.fill_batch_host(descs, host)
+            tf = time.perf_counter() - t
+            t = time.perf_counter()
+            res, cnt = ctx.validate_batch_host(descs, host)
+            tv = time.perf_counter() - t
+            assert cnt[1] == 0 and cnt[2] == units
+        rows.append((kind, nbytes / tf / 1e9, nbytes / tv / 1e9, 2 * nbytes / (tf + tv) / 1e9))
+        if kind == "pinned":
+            _lib.check(L.oval_pinned_free(ctx.handle, p))
+    print(f"# host-inclusive pattern rate, {n_obj} objects 4k-16k, {nbytes / 1e9:.2f} GB per pass, MI355X + PCIe Gen5 x16")
+    print("# fill = kernel + D2H, validate = H2D + kernel; layout creation, device allocation and free included")
+    print("# host buffer   fill GB/s   validate GB/s   combined GB/s")
+    for r in rows:
+        print("%-12s %10.1f %14.1f %14.1f" % r)
+
+
+if __name__ == "__main__":
+    main()
