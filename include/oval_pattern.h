@@ -65,6 +65,26 @@ int oval_pattern_valid_data_unit(int64_t unit_count, int64_t worker_id,
                                  const char* key, size_t key_len, int64_t write_count,
                                  const uint8_t* data, char* err, size_t err_cap);
 
+/* Batch forms of Generate / Valid (no counterpart in the reference): item i
+ * gets rcs[i] (0 nil, 1 error, <0 engine failure) and its error text at
+ * errs + i * err_stride.  Returns the lowest (most severe) engine status. */
+int oval_pattern_generate_batch(size_t n, const int64_t* data_sizes, const int64_t* worker_ids,
+                                const char* const* buckets, const size_t* bucket_lens,
+                                const char* const* keys, const size_t* key_lens,
+                                const int64_t* write_counts, uint8_t* const* outs,
+                                int* rcs, char* errs, size_t err_stride);
+int oval_pattern_valid_batch(size_t n, const int64_t* worker_ids, const char* const* buckets,
+                             const size_t* bucket_lens, const char* const* keys, const size_t* key_lens,
+                             const int64_t* sizes, const int64_t* write_counts,
+                             const uint8_t* const* bodies, const size_t* body_lens,
+                             int* rcs, char* errs, size_t err_stride);
+
+/* Micro-batching of concurrent single-object calls (worker goroutines call
+ * Generate / Valid one object at a time, internal/runner/worker.go:64-200):
+ * while enabled, calls arriving within window_us share one device launch. */
+void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes);
+void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs);
+
 /* pattern.dump — pattern.go:182-206; and encoding/hex.Dump which feeds it.
  * Both return the full length of the text and write at most cap-1 bytes + NUL. */
 size_t oval_pattern_dump(const char* text, size_t n, char* out, size_t cap);

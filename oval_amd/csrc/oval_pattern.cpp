@@ -8,8 +8,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <random>
+#include <thread>
 
 #include "../../include/oval_hip.h"
 #include "../../include/oval_pattern.h"
@@ -49,12 +51,25 @@ Object NewObject(int64_t objID)
 namespace pattern {
 
 // ---------------------------------------------------------------------------
-// engine: one context, one reusable layout, growable staging buffers
+// engine: one context, one reusable layout, growable staging buffers.  All
+// device work goes through run_jobs_locked(), which takes any number of
+// objects at once: the scalar API hands it one job, GenerateBatch/ValidBatch
+// and the micro-batcher hand it many.
 // ---------------------------------------------------------------------------
 namespace {
 
+struct Job {
+    bool is_fill = true;
+    oval_obj_desc desc{};          // body_offset is assigned by the runner
+    uint8_t* out = nullptr;        // fill: n_units * 256 bytes of host memory to receive the body
+    const uint8_t* in = nullptr;   // validate: n_units * 256 bytes of host memory holding the body
+    oval_obj_result res{};         // validate: the device's verdict
+    bool failed = false;           // the engine failed for the batch this job was in
+    bool done = false;             // micro-batcher: completion flag
+};
+
 struct Engine {
-    std::mutex mu;
+    std::mutex mu;                 // serialises use of ctx/layout/staging
     oval_ctx* ctx = nullptr;
     oval_layout* layout = nullptr;
     void* dev_body = nullptr;
@@ -63,10 +78,14 @@ struct Engine {
     size_t pinned_cap = 0;
     oval_obj_result* res_dev = nullptr;
     oval_obj_result* res_host = nullptr;   // pinned
+    size_t res_cap = 0;
+    std::vector<oval_obj_desc> descs;
+    std::string err;
+
+    std::mutex state_mu;           // clock and random source
     int64_t clock = -1;
     uint64_t rng[4] = {0, 0, 0, 0};
     bool seeded = false;
-    std::string err;
 };
 
 Engine g_engine;
@@ -114,20 +133,16 @@ int ensure_engine_locked(Engine& e, int device)
     int rc = oval_ctx_create(device, nullptr, &e.ctx);
     if (rc) return engine_fail(e, rc);
     rc = oval_layout_create(e.ctx, nullptr, 0, &e.layout);
-    if (!rc) rc = oval_dev_alloc(e.ctx, sizeof(oval_obj_result), (void**)&e.res_dev);
-    if (!rc) rc = oval_pinned_alloc(e.ctx, sizeof(oval_obj_result), (void**)&e.res_host);
     if (rc) {
         engine_fail(e, rc);
-        if (e.res_dev) oval_dev_free(e.ctx, e.res_dev);
-        if (e.layout) oval_layout_destroy(e.ctx, e.layout);
         oval_ctx_destroy(e.ctx);
-        e.ctx = nullptr; e.layout = nullptr; e.res_dev = nullptr; e.res_host = nullptr;
+        e.ctx = nullptr;
         return rc;
     }
     return OVAL_OK;
 }
 
-int ensure_buffers_locked(Engine& e, size_t bytes, bool want_pinned)
+int ensure_buffers_locked(Engine& e, size_t bytes, size_t n_results)
 {
     if (bytes > e.dev_cap) {
         if (e.dev_body) { oval_ctx_sync(e.ctx); oval_dev_free(e.ctx, e.dev_body); e.dev_body = nullptr; e.dev_cap = 0; }
@@ -137,12 +152,23 @@ int ensure_buffers_locked(Engine& e, size_t bytes, bool want_pinned)
         if (rc) return engine_fail(e, rc);
         e.dev_cap = cap;
     }
-    if (want_pinned && bytes > e.pinned_cap) {
+    if (bytes > e.pinned_cap) {
         if (e.pinned) { oval_ctx_sync(e.ctx); oval_pinned_free(e.ctx, e.pinned); e.pinned = nullptr; e.pinned_cap = 0; }
         size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
         int rc = oval_pinned_alloc(e.ctx, cap, (void**)&e.pinned);
         if (rc) return engine_fail(e, rc);
         e.pinned_cap = cap;
+    }
+    if (n_results > e.res_cap) {
+        oval_ctx_sync(e.ctx);
+        if (e.res_dev) oval_dev_free(e.ctx, e.res_dev);
+        if (e.res_host) oval_pinned_free(e.ctx, e.res_host);
+        e.res_dev = nullptr; e.res_host = nullptr; e.res_cap = 0;
+        const size_t cap = n_results < 64 ? 64 : n_results * 2;
+        int rc = oval_dev_alloc(e.ctx, cap * sizeof(oval_obj_result), (void**)&e.res_dev);
+        if (!rc) rc = oval_pinned_alloc(e.ctx, cap * sizeof(oval_obj_result), (void**)&e.res_host);
+        if (rc) return engine_fail(e, rc);
+        e.res_cap = cap;
     }
     return OVAL_OK;
 }
@@ -152,9 +178,125 @@ Error engine_error(const Engine& e)
     return Error::New("oval engine failure: " + e.err);
 }
 
-int64_t now_unix_micro(const Engine& e)
+// One pass (fill or validate) over the jobs of one kind.
+int run_pass_locked(Engine& e, Job* const* jobs, size_t n, bool fill)
 {
-    if (e.clock >= 0) return e.clock;
+    e.descs.clear();
+    uint64_t off = 0;
+    for (size_t i = 0; i < n; ++i) {
+        Job* j = jobs[i];
+        j->desc.body_offset = off;
+        off += (uint64_t)j->desc.n_units * dataUnitSize;
+        e.descs.push_back(j->desc);
+    }
+    if (off == 0) return OVAL_OK;
+    int rc = ensure_buffers_locked(e, off, fill ? 0 : n);
+    if (rc) return rc;
+    if ((rc = oval_layout_reset(e.ctx, e.layout, e.descs.data(), n))) return engine_fail(e, rc);
+    if (fill) {
+        if ((rc = oval_fill(e.ctx, e.layout, e.dev_body, e.dev_cap))) return engine_fail(e, rc);
+        if ((rc = oval_copy_d2h(e.ctx, e.pinned, e.dev_body, off))) return engine_fail(e, rc);
+        if ((rc = oval_ctx_sync(e.ctx))) return engine_fail(e, rc);
+        for (size_t i = 0; i < n; ++i)
+            std::memcpy(jobs[i]->out, e.pinned + jobs[i]->desc.body_offset,
+                        (size_t)jobs[i]->desc.n_units * dataUnitSize);
+    } else {
+        for (size_t i = 0; i < n; ++i)
+            std::memcpy(e.pinned + jobs[i]->desc.body_offset, jobs[i]->in,
+                        (size_t)jobs[i]->desc.n_units * dataUnitSize);
+        if ((rc = oval_copy_h2d(e.ctx, e.dev_body, e.pinned, off))) return engine_fail(e, rc);
+        if ((rc = oval_validate(e.ctx, e.layout, e.dev_body, e.dev_cap, e.res_dev, nullptr))) return engine_fail(e, rc);
+        if ((rc = oval_copy_d2h(e.ctx, e.res_host, e.res_dev, n * sizeof(oval_obj_result)))) return engine_fail(e, rc);
+        if ((rc = oval_ctx_sync(e.ctx))) return engine_fail(e, rc);
+        for (size_t i = 0; i < n; ++i) jobs[i]->res = e.res_host[i];
+    }
+    return OVAL_OK;
+}
+
+// Runs a mixed set of jobs: all fills in one launch, all validates in another.
+int run_jobs_locked(Engine& e, Job* const* jobs, size_t n)
+{
+    int rc = ensure_engine_locked(e, 0);
+    std::vector<Job*> fills, vals;
+    for (size_t i = 0; i < n; ++i) (jobs[i]->is_fill ? fills : vals).push_back(jobs[i]);
+    if (!rc && !fills.empty()) rc = run_pass_locked(e, fills.data(), fills.size(), true);
+    if (!rc && !vals.empty()) rc = run_pass_locked(e, vals.data(), vals.size(), false);
+    if (rc)
+        for (size_t i = 0; i < n; ++i) jobs[i]->failed = true;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------
+// micro-batcher: coalesces concurrent single-object calls (one per worker
+// thread, internal/runner/runner.go:186-214) into device batches.
+// ---------------------------------------------------------------------------
+struct Batcher {
+    std::mutex mu;
+    std::condition_variable work_cv, done_cv;
+    std::vector<Job*> queue;
+    size_t queued_bytes = 0;
+    bool enabled = false, stop = false;
+    int window_us = 100;
+    size_t max_bytes = 64u << 20;
+    std::thread thread;
+    uint64_t batches = 0, jobs = 0;   // statistics
+};
+
+Batcher g_batcher;
+
+void batcher_loop()
+{
+    Batcher& b = g_batcher;
+    std::unique_lock<std::mutex> lk(b.mu);
+    for (;;) {
+        b.work_cv.wait(lk, [&] { return b.stop || !b.queue.empty(); });
+        if (b.stop && b.queue.empty()) return;
+        // hold the door open for a short window so that callers arriving together share a launch
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b.window_us);
+        while (!b.stop && b.queued_bytes < b.max_bytes &&
+               b.work_cv.wait_until(lk, deadline) != std::cv_status::timeout) {
+        }
+        std::vector<Job*> batch;
+        batch.swap(b.queue);
+        b.queued_bytes = 0;
+        lk.unlock();
+        {
+            std::lock_guard<std::mutex> ek(g_engine.mu);
+            run_jobs_locked(g_engine, batch.data(), batch.size());
+        }
+        lk.lock();
+        b.batches++;
+        b.jobs += batch.size();
+        for (Job* j : batch) j->done = true;
+        b.done_cv.notify_all();
+    }
+}
+
+// Executes one job, through the batcher when it is enabled.
+void execute(Job& job)
+{
+    Batcher& b = g_batcher;
+    {
+        std::unique_lock<std::mutex> lk(b.mu);
+        if (b.enabled) {
+            b.queue.push_back(&job);
+            b.queued_bytes += (size_t)job.desc.n_units * dataUnitSize;
+            b.work_cv.notify_one();
+            b.done_cv.wait(lk, [&] { return job.done; });
+            return;
+        }
+    }
+    Job* p = &job;
+    std::lock_guard<std::mutex> ek(g_engine.mu);
+    run_jobs_locked(g_engine, &p, 1);
+}
+
+int64_t now_unix_micro()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_engine.state_mu);
+        if (g_engine.clock >= 0) return g_engine.clock;
+    }
     using namespace std::chrono;
     return duration_cast<microseconds>(system_clock::now().time_since_epoch()).count();
 }
@@ -165,8 +307,8 @@ std::string truncate_bucket(const std::string& b)
     return b.size() > (size_t)object::MaxBucketNameLength ? b.substr(0, object::MaxBucketNameLength) : b;
 }
 
-// Builds the one descriptor of a single-object call.  Returns OVAL_E_FIELD (and
-// the formatted unit length) when the names do not format to 28 bytes.
+// Builds the descriptor of a single-object call and reports the length the
+// reference's formatting would give the unit (256 unless the names overflow).
 int make_desc(const std::string& bucket16, const object::Object* obj, int64_t workerID, int64_t unixMicro,
               uint32_t firstUnit, uint32_t nUnits, oval_obj_desc* d, size_t* unit_len)
 {
@@ -176,34 +318,6 @@ int make_desc(const std::string& bucket16, const object::Object* obj, int64_t wo
                 (dataUnitSize - (object::MaxBucketNameLength + object::MaxKeyLength + dataUnitHeaderSizeWithoutBucketAndKey));
     return oval_desc_init(d, bucket16.data(), bucket16.size(), obj->Key.data(), obj->Key.size(), obj->WriteCount,
                           workerID, (uint64_t)unixMicro, 0, firstUnit, nUnits);
-}
-
-// Device fill of one descriptor into `out` (host memory).
-Error fill_one_locked(Engine& e, const oval_obj_desc& d, uint8_t* out)
-{
-    const size_t bytes = (size_t)d.n_units * dataUnitSize;
-    if (bytes == 0) return Error::Nil();
-    int rc = ensure_buffers_locked(e, bytes, false);
-    if (!rc) { rc = oval_layout_reset(e.ctx, e.layout, &d, 1); if (rc) engine_fail(e, rc); }
-    if (!rc) { rc = oval_fill(e.ctx, e.layout, e.dev_body, e.dev_cap); if (rc) engine_fail(e, rc); }
-    if (!rc) { rc = oval_copy_d2h(e.ctx, out, e.dev_body, bytes); if (rc) engine_fail(e, rc); }
-    if (!rc) { rc = oval_ctx_sync(e.ctx); if (rc) engine_fail(e, rc); }
-    return rc ? engine_error(e) : Error::Nil();
-}
-
-// Device validate of `n_units` units held in the pinned buffer.
-Error validate_one_locked(Engine& e, const oval_obj_desc& d, oval_obj_result* res)
-{
-    const size_t bytes = (size_t)d.n_units * dataUnitSize;
-    int rc = oval_layout_reset(e.ctx, e.layout, &d, 1);
-    if (rc) { engine_fail(e, rc); return engine_error(e); }
-    rc = oval_copy_h2d(e.ctx, e.dev_body, e.pinned, bytes);
-    if (!rc) rc = oval_validate(e.ctx, e.layout, e.dev_body, e.dev_cap, e.res_dev, nullptr);
-    if (!rc) rc = oval_copy_d2h(e.ctx, e.res_host, e.res_dev, sizeof(oval_obj_result));
-    if (!rc) rc = oval_ctx_sync(e.ctx);
-    if (rc) { engine_fail(e, rc); return engine_error(e); }
-    *res = *e.res_host;
-    return Error::Nil();
 }
 
 std::string trimmed(const uint8_t* p, int n)
@@ -289,8 +403,36 @@ int Init(int deviceID)
     return ensure_engine_locked(g_engine, deviceID);
 }
 
+void SetMicroBatching(bool enable, int windowMicros, size_t maxBytes)
+{
+    Batcher& b = g_batcher;
+    std::unique_lock<std::mutex> lk(b.mu);
+    if (windowMicros > 0) b.window_us = windowMicros;
+    if (maxBytes > 0) b.max_bytes = maxBytes;
+    if (enable && !b.enabled) {
+        b.stop = false;
+        b.enabled = true;
+        b.thread = std::thread(batcher_loop);
+    } else if (!enable && b.enabled) {
+        b.enabled = false;       // new callers take the direct path; queued ones are still served
+        b.stop = true;
+        b.work_cv.notify_all();
+        std::thread t = std::move(b.thread);
+        lk.unlock();
+        if (t.joinable()) t.join();
+    }
+}
+
+void MicroBatchingStats(uint64_t* batches, uint64_t* jobs)
+{
+    std::lock_guard<std::mutex> lk(g_batcher.mu);
+    if (batches) *batches = g_batcher.batches;
+    if (jobs) *jobs = g_batcher.jobs;
+}
+
 void Shutdown()
 {
+    SetMicroBatching(false, 0, 0);
     Engine& e = g_engine;
     std::lock_guard<std::mutex> lk(e.mu);
     if (!e.ctx) return;
@@ -302,18 +444,18 @@ void Shutdown()
     if (e.layout) oval_layout_destroy(e.ctx, e.layout);
     oval_ctx_destroy(e.ctx);
     e.ctx = nullptr; e.layout = nullptr; e.dev_body = nullptr; e.pinned = nullptr;
-    e.res_dev = nullptr; e.res_host = nullptr; e.dev_cap = 0; e.pinned_cap = 0;
+    e.res_dev = nullptr; e.res_host = nullptr; e.dev_cap = 0; e.pinned_cap = 0; e.res_cap = 0;
 }
 
 void SetClock(int64_t unixMicro)
 {
-    std::lock_guard<std::mutex> lk(g_engine.mu);
+    std::lock_guard<std::mutex> lk(g_engine.state_mu);
     g_engine.clock = unixMicro;
 }
 
 void Seed(uint64_t seed)
 {
-    std::lock_guard<std::mutex> lk(g_engine.mu);
+    std::lock_guard<std::mutex> lk(g_engine.state_mu);
     seed_locked(g_engine, seed);
 }
 
@@ -353,28 +495,32 @@ std::pair<int64_t, Error> DecideSize(int64_t minSize, int64_t maxSize)
 {
     double y;
     {
-        std::lock_guard<std::mutex> lk(g_engine.mu);
+        std::lock_guard<std::mutex> lk(g_engine.state_mu);
         y = float64_locked(g_engine);
     }
     return DecideSizeFrom(minSize, maxSize, y);
 }
 
 // ---------------------------------------------------------------------------
-// Generate — pattern.go:73-92
+// Generate — pattern.go:73-92, in three steps so that single calls and batches
+// share them: prepare (host checks, descriptor), device pass, nothing to finish.
 // ---------------------------------------------------------------------------
-Error GenerateInto(int64_t dataSize, int64_t workerID, const std::string& bucketName,
-                   const object::Object* obj, uint8_t* out)
+namespace {
+
+// Returns nil and a job with n_units > 0 when there is device work to do; nil
+// and n_units == 0 for an empty body; an error otherwise.
+Error prepare_generate(int64_t dataSize, int64_t workerID, const std::string& bucketName,
+                       const object::Object* obj, uint8_t* out, Job& job)
 {
     const std::string bucket16 = truncate_bucket(bucketName);
+    job.is_fill = true;
+    job.out = out;
+    job.desc.n_units = 0;
     if (dataSize < 0) return Error::New("negative data size");   // make([]byte, 0, dataSize) panics in Go
     const int64_t nUnits = dataSize / dataUnitSize;
     if (nUnits > 0xFFFFFFF0ll) return Error::New("data size beyond the engine's 1 TiB limit");
-
-    Engine& e = g_engine;
-    std::lock_guard<std::mutex> lk(e.mu);
-    oval_obj_desc d;
     size_t unit_len = 0;
-    const int rc_desc = make_desc(bucket16, obj, workerID, now_unix_micro(e), 0, (uint32_t)nUnits, &d, &unit_len);
+    const int rc_desc = make_desc(bucket16, obj, workerID, now_unix_micro(), 0, (uint32_t)nUnits, &job.desc, &unit_len);
     // pattern.go:87-89: the length check that catches over-long fields and
     // sizes that are not a multiple of 256
     const int64_t produced = nUnits * (int64_t)unit_len;
@@ -382,12 +528,26 @@ Error GenerateInto(int64_t dataSize, int64_t workerID, const std::string& bucket
         char buf[128];
         std::snprintf(buf, sizeof buf, "generated data size is wrong. (expected: %lld, actual: %lld)",
                       (long long)dataSize, (long long)produced);
+        job.desc.n_units = 0;
         return Error::New(buf);
     }
-    if (nUnits == 0) return Error::Nil();
-    if (rc_desc) { e.err = oval_last_error(); return engine_error(e); }
-    if (int rc = ensure_engine_locked(e, 0)) { (void)rc; return engine_error(e); }
-    return fill_one_locked(e, d, out);
+    if (nUnits > 0 && rc_desc) {
+        job.desc.n_units = 0;
+        return Error::New(std::string("oval engine failure: ") + oval_last_error());
+    }
+    return Error::Nil();
+}
+
+}  // namespace
+
+Error GenerateInto(int64_t dataSize, int64_t workerID, const std::string& bucketName,
+                   const object::Object* obj, uint8_t* out)
+{
+    Job job;
+    Error err = prepare_generate(dataSize, workerID, bucketName, obj, out, job);
+    if (!err.nil() || job.desc.n_units == 0) return err;
+    execute(job);
+    return job.failed ? engine_error(g_engine) : Error::Nil();
 }
 
 std::pair<std::vector<uint8_t>, Error> Generate(int64_t dataSize, int64_t workerID,
@@ -400,6 +560,24 @@ std::pair<std::vector<uint8_t>, Error> Generate(int64_t dataSize, int64_t worker
     return {std::move(data), err};
 }
 
+std::vector<Error> GenerateBatch(const std::vector<GenerateItem>& items)
+{
+    std::vector<Error> errs(items.size());
+    std::vector<Job> jobs(items.size());
+    std::vector<Job*> run;
+    for (size_t i = 0; i < items.size(); ++i) {
+        const GenerateItem& it = items[i];
+        errs[i] = prepare_generate(it.dataSize, it.workerID, it.bucketName, it.obj, it.out, jobs[i]);
+        if (errs[i].nil() && jobs[i].desc.n_units > 0) run.push_back(&jobs[i]);
+    }
+    if (!run.empty()) {
+        std::lock_guard<std::mutex> ek(g_engine.mu);
+        if (run_jobs_locked(g_engine, run.data(), run.size()))
+            for (Job* j : run) errs[(size_t)(j - jobs.data())] = engine_error(g_engine);
+    }
+    return errs;
+}
+
 // ---------------------------------------------------------------------------
 // generateDataUnit — pattern.go:94-116
 // ---------------------------------------------------------------------------
@@ -407,19 +585,16 @@ std::pair<std::vector<uint8_t>, Error> generateDataUnit(int64_t unitCount, int64
                                                         const std::string& bucketName,
                                                         const object::Object* obj)
 {
-    Engine& e = g_engine;
-    std::lock_guard<std::mutex> lk(e.mu);
-    oval_obj_desc d;
-    size_t unit_len = 0;
     // generateDataUnit itself does not truncate the bucket name; names that do
     // not format to 28 bytes would give a unit of another length, which the
     // engine does not produce
-    const int rc_desc = bucketName.size() > (size_t)object::MaxBucketNameLength
-                            ? OVAL_E_FIELD
-                            : make_desc(bucketName, obj, workerID, now_unix_micro(e), (uint32_t)unitCount, 1, &d, &unit_len);
-    if (bucketName.size() > (size_t)object::MaxBucketNameLength)
-        unit_len = go_padded_len((const unsigned char*)bucketName.data(), bucketName.size(), 16) +
-                   go_padded_len((const unsigned char*)obj->Key.data(), obj->Key.size(), 12) + 228;
+    Job job;
+    job.is_fill = true;
+    size_t unit_len = go_padded_len((const unsigned char*)bucketName.data(), bucketName.size(), 16) +
+                      go_padded_len((const unsigned char*)obj->Key.data(), obj->Key.size(), 12) + 228;
+    int rc_desc = OVAL_E_FIELD;
+    if (unit_len == (size_t)dataUnitSize)
+        rc_desc = make_desc(bucketName, obj, workerID, now_unix_micro(), (uint32_t)unitCount, 1, &job.desc, &unit_len);
     if (rc_desc || unit_len != (size_t)dataUnitSize) {
         char buf[160];
         std::snprintf(buf, sizeof buf,
@@ -427,11 +602,11 @@ std::pair<std::vector<uint8_t>, Error> generateDataUnit(int64_t unitCount, int64
                       unit_len, dataUnitSize);
         return {{}, Error::New(buf)};
     }
-    if (ensure_engine_locked(e, 0)) return {{}, engine_error(e)};
     std::vector<uint8_t> unit(dataUnitSize);
-    Error err = fill_one_locked(e, d, unit.data());
-    if (!err.nil()) unit.clear();
-    return {std::move(unit), err};
+    job.out = unit.data();
+    execute(job);
+    if (job.failed) return {{}, engine_error(g_engine)};
+    return {std::move(unit), Error::Nil()};
 }
 
 // ---------------------------------------------------------------------------
@@ -439,34 +614,21 @@ std::pair<std::vector<uint8_t>, Error> generateDataUnit(int64_t unitCount, int64
 // ---------------------------------------------------------------------------
 namespace {
 
-// validDataUnit with the engine lock held.  `data` may be e.pinned itself.
-Error valid_unit_locked(Engine& e, int64_t unitCount, int64_t workerID, const std::string& expectedBucketName,
-                        const object::Object* obj, const uint8_t* data)
+// Descriptor for validating `nUnits` units starting at unitCount `firstUnit`.
+// An expected name longer than its field can never equal the trimmed field
+// (pattern.go:140,147): that name is wrong whatever the unit holds; the other
+// fields are still checked on the device.  Returns the mask of such names.
+uint32_t validation_desc(const std::string& expectedBucketName, const object::Object* obj, int64_t workerID,
+                         uint32_t firstUnit, uint32_t nUnits, oval_obj_desc* d, bool* ok)
 {
-    if (ensure_engine_locked(e, 0)) return engine_error(e);
-    if (ensure_buffers_locked(e, dataUnitSize, true)) return engine_error(e);
-    if (data != e.pinned) std::memcpy(e.pinned, data, dataUnitSize);
-    // An expected name longer than its field can never equal the trimmed field
-    // (pattern.go:140,147): that name is wrong whatever the unit holds.  The
-    // other fields are still checked on the device.
     uint32_t forced = 0;
     std::string b = expectedBucketName;
     object::Object o = *obj;
     if (b.size() > (size_t)object::MaxBucketNameLength) { b.clear(); forced |= OVAL_BAD_BUCKET; }
     if (o.Key.size() > (size_t)object::MaxKeyLength) { o.Key.clear(); forced |= OVAL_BAD_KEY; }
-    oval_obj_desc d;
     size_t unit_len = 0;
-    if (make_desc(b, &o, workerID, 0, (uint32_t)unitCount, 1, &d, &unit_len)) {
-        e.err = oval_last_error();
-        return engine_error(e);
-    }
-    oval_obj_result r;
-    Error err = validate_one_locked(e, d, &r);
-    if (!err.nil()) return err;
-    uint32_t mask = (r.first_bad_unit == OVAL_NO_BAD_UNIT) ? 0u : r.first_bad_fields;
-    mask |= forced;
-    if (mask == 0) return Error::Nil();
-    return Error::New(unit_error_text(mask, unitCount, workerID, expectedBucketName, obj, e.pinned));
+    *ok = make_desc(b, &o, workerID, 0, firstUnit, nUnits, d, &unit_len) == OVAL_OK;
+    return forced;
 }
 
 }  // namespace
@@ -474,64 +636,135 @@ Error valid_unit_locked(Engine& e, int64_t unitCount, int64_t workerID, const st
 Error validDataUnit(int64_t unitCount, int64_t workerID, const std::string& expectedBucketName,
                     const object::Object* obj, const uint8_t* data)
 {
-    Engine& e = g_engine;
-    std::lock_guard<std::mutex> lk(e.mu);
-    return valid_unit_locked(e, unitCount, workerID, expectedBucketName, obj, data);
+    Job job;
+    job.is_fill = false;
+    job.in = data;
+    bool ok = false;
+    const uint32_t forced = validation_desc(expectedBucketName, obj, workerID, (uint32_t)unitCount, 1, &job.desc, &ok);
+    if (!ok) return Error::New(std::string("oval engine failure: ") + oval_last_error());
+    execute(job);
+    if (job.failed) return engine_error(g_engine);
+    uint32_t mask = (job.res.first_bad_unit == OVAL_NO_BAD_UNIT) ? 0u : job.res.first_bad_fields;
+    mask |= forced;
+    if (mask == 0) return Error::Nil();
+    return Error::New(unit_error_text(mask, unitCount, workerID, expectedBucketName, obj, data));
 }
 
 // ---------------------------------------------------------------------------
-// Valid — pattern.go:118-134
+// Valid — pattern.go:118-134: read the body, device pass over the complete
+// units, then the reference's precedence (a bad unit wins over a short read).
 // ---------------------------------------------------------------------------
-Error Valid(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
-            Reader& reader)
+namespace {
+
+struct ValidState {
+    std::string bucket16;
+    int64_t nUnits = 0;
+    size_t avail = 0, complete = 0;
+    uint32_t forced = 0;
+    bool has_job = false;
+};
+
+Error prepare_valid(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
+                    const uint8_t* body, size_t avail, ValidState& st, Job& job)
 {
-    const std::string bucket16 = truncate_bucket(expectedBucketName);
-    const int64_t nUnits = obj->Size / dataUnitSize;
-    if (nUnits <= 0) return Error::Nil();                    // the loop at :123 does not run
-    if (nUnits > 0xFFFFFFF0ll) return Error::New("object size beyond the engine's 1 TiB limit");
-    const size_t want = (size_t)nUnits * dataUnitSize;
+    st.bucket16 = truncate_bucket(expectedBucketName);
+    st.nUnits = obj->Size / dataUnitSize;
+    st.has_job = false;
+    if (st.nUnits <= 0) return Error::Nil();                 // the loop at :123 does not run
+    if (st.nUnits > 0xFFFFFFF0ll) return Error::New("object size beyond the engine's 1 TiB limit");
+    const size_t want = (size_t)st.nUnits * dataUnitSize;
+    st.avail = avail < want ? avail : want;
+    st.complete = st.avail / dataUnitSize;
+    if (st.complete == 0) return Error::Nil();
+    job.is_fill = false;
+    job.in = body;
+    bool ok = false;
+    st.forced = validation_desc(st.bucket16, obj, workerID, 0, (uint32_t)st.complete, &job.desc, &ok);
+    if (!ok) return Error::New(std::string("oval engine failure: ") + oval_last_error());
+    st.has_job = true;
+    return Error::Nil();
+}
 
-    Engine& e = g_engine;
-    std::lock_guard<std::mutex> lk(e.mu);
-    if (ensure_engine_locked(e, 0)) return engine_error(e);
-    if (ensure_buffers_locked(e, want, true)) return engine_error(e);
-
-    // io.ReadFull unit by unit (:124) == read until `want` bytes or EOF
-    size_t avail = 0;
-    while (avail < want) {
-        const size_t n = reader.Read(e.pinned + avail, want - avail);
-        if (n == 0) break;
-        avail += n;
-    }
-    const size_t complete = avail / dataUnitSize;
-
-    if (complete > 0) {
-        // a key longer than its field fails in the very first unit (pattern.go:147)
-        if (obj->Key.size() > (size_t)object::MaxKeyLength)
-            return valid_unit_locked(e, 0, workerID, bucket16, obj, e.pinned);
-        oval_obj_desc d;
-        size_t unit_len = 0;
-        if (make_desc(bucket16, obj, workerID, 0, 0, (uint32_t)complete, &d, &unit_len)) {
-            e.err = oval_last_error();
-            return engine_error(e);
+Error finish_valid(int64_t workerID, const object::Object* obj, const uint8_t* body, const ValidState& st,
+                   const Job& job)
+{
+    if (st.nUnits <= 0) return Error::Nil();
+    if (st.has_job) {
+        if (job.failed) return engine_error(g_engine);
+        if (st.forced) {
+            // a name longer than its field fails in the very first unit; the
+            // device still says which of unit 0's other fields are wrong
+            uint32_t mask = st.forced;
+            if (job.res.first_bad_unit == 0) mask |= job.res.first_bad_fields;
+            return Error::New(unit_error_text(mask, 0, workerID, st.bucket16, obj, body));
         }
-        oval_obj_result r;
-        Error err = validate_one_locked(e, d, &r);
-        if (!err.nil()) return err;
-        if (r.first_bad_unit != OVAL_NO_BAD_UNIT) {
-            const uint8_t* unit = e.pinned + (size_t)r.first_bad_unit * dataUnitSize;
-            return Error::New(unit_error_text(r.first_bad_fields, r.first_bad_unit, workerID, bucket16, obj, unit));
+        if (job.res.first_bad_unit != OVAL_NO_BAD_UNIT) {
+            const uint8_t* unit = body + (size_t)job.res.first_bad_unit * dataUnitSize;
+            return Error::New(unit_error_text(job.res.first_bad_fields, job.res.first_bad_unit, workerID,
+                                              st.bucket16, obj, unit));
         }
     }
-    if (complete < (size_t)nUnits) {
+    if (st.complete < (size_t)st.nUnits) {
         // :125-127 the unit that could not be read in full
-        const size_t n = avail - complete * dataUnitSize;
+        const size_t n = st.avail - st.complete * dataUnitSize;
         char head[96];
         std::snprintf(head, sizeof head, "could not read some data. (expected: %dbyte, actual: %zubyte)\n",
                       dataUnitSize, n);
-        return Error::New(std::string(head) + dump(hexDump(e.pinned + complete * dataUnitSize, n)));
+        return Error::New(std::string(head) + dump(hexDump(body + st.complete * dataUnitSize, n)));
     }
     return Error::Nil();
+}
+
+}  // namespace
+
+Error ValidBytes(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
+                 const uint8_t* body, size_t bodyLen)
+{
+    ValidState st;
+    Job job;
+    Error err = prepare_valid(workerID, expectedBucketName, obj, body, bodyLen, st, job);
+    if (!err.nil()) return err;
+    if (st.has_job) execute(job);
+    return finish_valid(workerID, obj, body, st, job);
+}
+
+Error Valid(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
+            Reader& reader)
+{
+    const int64_t nUnits = obj->Size / dataUnitSize;
+    if (nUnits <= 0) return Error::Nil();
+    if (nUnits > 0xFFFFFFF0ll) return Error::New("object size beyond the engine's 1 TiB limit");
+    const size_t want = (size_t)nUnits * dataUnitSize;
+    // io.ReadFull unit by unit (:124) == read until `want` bytes or EOF
+    std::vector<uint8_t> body(want);
+    size_t avail = 0;
+    while (avail < want) {
+        const size_t n = reader.Read(body.data() + avail, want - avail);
+        if (n == 0) break;
+        avail += n;
+    }
+    return ValidBytes(workerID, expectedBucketName, obj, body.data(), avail);
+}
+
+std::vector<Error> ValidBatch(const std::vector<ValidItem>& items)
+{
+    std::vector<Error> errs(items.size());
+    std::vector<Job> jobs(items.size());
+    std::vector<ValidState> sts(items.size());
+    std::vector<Job*> run;
+    for (size_t i = 0; i < items.size(); ++i) {
+        const ValidItem& it = items[i];
+        errs[i] = prepare_valid(it.workerID, it.expectedBucketName, it.obj, it.body, it.bodyLen, sts[i], jobs[i]);
+        if (errs[i].nil() && sts[i].has_job) run.push_back(&jobs[i]);
+    }
+    if (!run.empty()) {
+        std::lock_guard<std::mutex> ek(g_engine.mu);
+        run_jobs_locked(g_engine, run.data(), run.size());
+    }
+    for (size_t i = 0; i < items.size(); ++i)
+        if (errs[i].nil())
+            errs[i] = finish_valid(items[i].workerID, items[i].obj, items[i].body, sts[i], jobs[i]);
+    return errs;
 }
 
 // ---------------------------------------------------------------------------
@@ -691,8 +924,7 @@ int oval_pattern_valid(int64_t worker_id, const char* bucket, size_t bucket_len,
 {
     const oval::object::Object obj = make_obj(key, key_len, size, write_count);
     const std::string b(bucket ? bucket : "", bucket_len);
-    oval::pattern::BytesReader rd(body, body_len);
-    return put_error(oval::pattern::Valid(worker_id, b, &obj, rd), err, err_cap);
+    return put_error(oval::pattern::ValidBytes(worker_id, b, &obj, body, body_len), err, err_cap);
 }
 
 int oval_pattern_valid_data_unit(int64_t unit_count, int64_t worker_id, const char* bucket, size_t bucket_len,
@@ -702,6 +934,66 @@ int oval_pattern_valid_data_unit(int64_t unit_count, int64_t worker_id, const ch
     const oval::object::Object obj = make_obj(key, key_len, 0, write_count);
     const std::string b(bucket ? bucket : "", bucket_len);
     return put_error(oval::pattern::validDataUnit(unit_count, worker_id, b, &obj, data), err, err_cap);
+}
+
+void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes)
+{
+    oval::pattern::SetMicroBatching(enable != 0, window_us, max_bytes);
+}
+
+void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs)
+{
+    oval::pattern::MicroBatchingStats(batches, jobs);
+}
+
+int oval_pattern_generate_batch(size_t n, const int64_t* data_sizes, const int64_t* worker_ids,
+                                const char* const* buckets, const size_t* bucket_lens, const char* const* keys,
+                                const size_t* key_lens, const int64_t* write_counts, uint8_t* const* outs,
+                                int* rcs, char* errs, size_t err_stride)
+{
+    std::vector<oval::object::Object> objs(n);
+    std::vector<oval::pattern::GenerateItem> items(n);
+    for (size_t i = 0; i < n; ++i) {
+        objs[i] = make_obj(keys[i], key_lens[i], 0, write_counts[i]);
+        items[i].dataSize = data_sizes[i];
+        items[i].workerID = worker_ids[i];
+        items[i].bucketName.assign(buckets[i] ? buckets[i] : "", bucket_lens[i]);
+        items[i].obj = &objs[i];
+        items[i].out = outs[i];
+    }
+    const std::vector<oval::Error> r = oval::pattern::GenerateBatch(items);
+    int worst = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const int rc = put_error(r[i], errs ? errs + i * err_stride : nullptr, errs ? err_stride : 0);
+        if (rcs) rcs[i] = rc;
+        if (rc < worst) worst = rc;
+    }
+    return worst;
+}
+
+int oval_pattern_valid_batch(size_t n, const int64_t* worker_ids, const char* const* buckets,
+                             const size_t* bucket_lens, const char* const* keys, const size_t* key_lens,
+                             const int64_t* sizes, const int64_t* write_counts, const uint8_t* const* bodies,
+                             const size_t* body_lens, int* rcs, char* errs, size_t err_stride)
+{
+    std::vector<oval::object::Object> objs(n);
+    std::vector<oval::pattern::ValidItem> items(n);
+    for (size_t i = 0; i < n; ++i) {
+        objs[i] = make_obj(keys[i], key_lens[i], sizes[i], write_counts[i]);
+        items[i].workerID = worker_ids[i];
+        items[i].expectedBucketName.assign(buckets[i] ? buckets[i] : "", bucket_lens[i]);
+        items[i].obj = &objs[i];
+        items[i].body = bodies[i];
+        items[i].bodyLen = body_lens[i];
+    }
+    const std::vector<oval::Error> r = oval::pattern::ValidBatch(items);
+    int worst = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const int rc = put_error(r[i], errs ? errs + i * err_stride : nullptr, errs ? err_stride : 0);
+        if (rcs) rcs[i] = rc;
+        if (rc < worst) worst = rc;
+    }
+    return worst;
 }
 
 size_t oval_pattern_dump(const char* text, size_t n, char* out, size_t cap)

@@ -88,6 +88,30 @@ std::pair<std::vector<uint8_t>, Error> generateDataUnit(int64_t unitCount, int64
 Error Valid(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
             Reader& reader);
 
+// Valid over a body that is already in memory: body[0, bodyLen) is what the
+// reader would deliver.
+Error ValidBytes(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
+                 const uint8_t* body, size_t bodyLen);
+
+// Batch forms (no counterpart in the reference): the same results as calling
+// Generate / Valid once per item, with one device launch per kind.
+struct GenerateItem {
+    int64_t dataSize = 0;
+    int64_t workerID = 0;
+    std::string bucketName;
+    const object::Object* obj = nullptr;
+    uint8_t* out = nullptr;            // dataSize bytes
+};
+struct ValidItem {
+    int64_t workerID = 0;
+    std::string expectedBucketName;
+    const object::Object* obj = nullptr;
+    const uint8_t* body = nullptr;     // what the reader would deliver
+    size_t bodyLen = 0;
+};
+std::vector<Error> GenerateBatch(const std::vector<GenerateItem>& items);
+std::vector<Error> ValidBatch(const std::vector<ValidItem>& items);
+
 // pattern.go:136-180
 Error validDataUnit(int64_t unitCount, int64_t workerID, const std::string& expectedBucketName,
                     const object::Object* obj, const uint8_t* data /* 256 bytes */);
@@ -102,6 +126,11 @@ void Shutdown();
 void SetClock(int64_t unixMicro);   // >= 0 pins time.Now().UnixMicro(); < 0 = wall clock
 void Seed(uint64_t seed);           // source of rand.Float64() in DecideSize
 const std::string& LastEngineError();
+// Micro-batching: while enabled, concurrent Generate / Valid calls (one per
+// worker thread, internal/runner/runner.go:186-214) that arrive within
+// `windowMicros` of each other share one device launch.  Results are identical.
+void SetMicroBatching(bool enable, int windowMicros = 100, size_t maxBytes = 64u << 20);
+void MicroBatchingStats(uint64_t* batches, uint64_t* jobs);
 
 }  // namespace pattern
 }  // namespace oval

@@ -111,6 +111,78 @@ def validDataUnit(unitCount: int, workerID: int, expectedBucketName, obj: Object
     _raise(rc, err)
 
 
+def set_batching(enable: bool, window_us: int = 100, max_bytes: int = 64 << 20) -> None:
+    """Coalesce concurrent Generate / Valid calls from different threads into
+    shared device launches (results are unchanged)."""
+    _lib.lib().oval_pattern_set_batching(1 if enable else 0, window_us, max_bytes)
+
+
+def batching_stats():
+    b, j = C.c_uint64(), C.c_uint64()
+    _lib.lib().oval_pattern_batching_stats(C.byref(b), C.byref(j))
+    return b.value, j.value
+
+
+def _name_arrays(names):
+    bs = [_b(x) for x in names]
+    ptrs = (C.c_char_p * len(bs))(*bs)
+    lens = (C.c_size_t * len(bs))(*[len(x) for x in bs])
+    return bs, ptrs, lens
+
+
+def _errors(n, rcs, errs, stride):
+    out = []
+    for i in range(n):
+        if rcs[i] == 0:
+            out.append(None)
+            continue
+        text = errs.raw[i * stride:(i + 1) * stride].split(b"\0", 1)[0].decode("utf-8", "surrogateescape")
+        out.append(OvalError(text) if rcs[i] < 0 else PatternError(text))
+    return out
+
+
+def GenerateBatch(items):
+    """items: sequence of (dataSize, workerID, bucketName, Object).  One device
+    launch for all of them.  Returns a list with, per item, the generated bytes
+    or the PatternError that Generate would have returned."""
+    n = len(items)
+    if n == 0:
+        return []
+    sizes = (C.c_int64 * n)(*[it[0] for it in items])
+    wids = (C.c_int64 * n)(*[it[1] for it in items])
+    _bk, bptr, blen = _name_arrays([it[2] for it in items])
+    _kk, kptr, klen = _name_arrays([it[3].Key for it in items])
+    wcs = (C.c_int64 * n)(*[it[3].WriteCount for it in items])
+    outs = [np.empty(max(it[0], 1), dtype=np.uint8) for it in items]
+    optr = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    rcs = (C.c_int * n)()
+    errs = C.create_string_buffer(n * 512)
+    _lib.lib().oval_pattern_generate_batch(n, sizes, wids, bptr, blen, kptr, klen, wcs, optr, rcs, errs, 512)
+    es = _errors(n, rcs, errs, 512)
+    return [es[i] if es[i] is not None else outs[i][:items[i][0]].tobytes() for i in range(n)]
+
+
+def ValidBatch(items):
+    """items: sequence of (workerID, expectedBucketName, Object, body bytes).
+    Returns a list of None (nil) or the PatternError Valid would have returned."""
+    n = len(items)
+    if n == 0:
+        return []
+    wids = (C.c_int64 * n)(*[it[0] for it in items])
+    _bk, bptr, blen = _name_arrays([it[1] for it in items])
+    _kk, kptr, klen = _name_arrays([it[2].Key for it in items])
+    sizes = (C.c_int64 * n)(*[it[2].Size for it in items])
+    wcs = (C.c_int64 * n)(*[it[2].WriteCount for it in items])
+    bodies = [np.frombuffer(_b(it[3]), dtype=np.uint8) if not isinstance(it[3], np.ndarray)
+              else np.ascontiguousarray(it[3], dtype=np.uint8) for it in items]
+    bp = (C.c_void_p * n)(*[(b.ctypes.data if b.size else None) for b in bodies])
+    bl = (C.c_size_t * n)(*[b.size for b in bodies])
+    rcs = (C.c_int * n)()
+    errs = C.create_string_buffer(n * _ERR_CAP)
+    _lib.lib().oval_pattern_valid_batch(n, wids, bptr, blen, kptr, klen, sizes, wcs, bp, bl, rcs, errs, _ERR_CAP)
+    return _errors(n, rcs, errs, _ERR_CAP)
+
+
 def hexDump(data) -> str:
     d = _b(data)
     cap = 80 * (len(d) // 16 + 2)
