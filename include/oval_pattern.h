@@ -59,6 +59,17 @@ int oval_pattern_valid(int64_t worker_id, const char* bucket, size_t bucket_len,
                        const char* key, size_t key_len, int64_t size, int64_t write_count,
                        const uint8_t* body, size_t body_len, char* err, size_t err_cap);
 
+/* pattern.Valid with a real io.Reader: `read` is called like Reader.Read
+ * (returns the number of bytes stored in p, 0 for EOF or error) until
+ * obj.Size / 256 units have been consumed or a bad unit was found.  The body
+ * is validated chunk by chunk (oval_pattern_set_stream_chunk, default 32 MiB),
+ * so its full size never has to be resident anywhere. */
+typedef size_t (*oval_read_fn)(void* user, uint8_t* p, size_t n);
+int oval_pattern_valid_stream(int64_t worker_id, const char* bucket, size_t bucket_len,
+                              const char* key, size_t key_len, int64_t size, int64_t write_count,
+                              oval_read_fn read, void* user, char* err, size_t err_cap);
+void oval_pattern_set_stream_chunk(size_t bytes);
+
 /* pattern.validDataUnit — pattern.go:136-180.  data holds 256 bytes. */
 int oval_pattern_valid_data_unit(int64_t unit_count, int64_t worker_id,
                                  const char* bucket, size_t bucket_len,

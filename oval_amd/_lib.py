@@ -102,6 +102,8 @@ SIGNATURES = {
     "oval_pattern_valid_data_unit": (_int, [_i64, _i64, _cp, _sz, _cp, _sz, _i64, _vp, _cp, _sz]),
     "oval_pattern_generate_batch": (_int, [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "oval_pattern_valid_batch": (_int, [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "oval_pattern_valid_stream": (_int, [_i64, _cp, _sz, _cp, _sz, _i64, _i64, _vp, _vp, _cp, _sz]),
+    "oval_pattern_set_stream_chunk": (None, [_sz]),
     "oval_pattern_set_batching": (None, [_int, _int, _sz]),
     "oval_pattern_batching_stats": (None, [C.POINTER(_u64), C.POINTER(_u64)]),
     "oval_pattern_dump": (_sz, [_cp, _sz, _cp, _sz]),

@@ -4,6 +4,7 @@
 // host only formats names, moves bytes and words the reference's error text.
 #include "oval_pattern.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -236,7 +237,7 @@ struct Batcher {
     std::vector<Job*> queue;
     size_t queued_bytes = 0;
     bool enabled = false, stop = false;
-    int window_us = 100;
+    int window_us = 0;
     size_t max_bytes = 64u << 20;
     std::thread thread;
     uint64_t batches = 0, jobs = 0;   // statistics
@@ -251,10 +252,14 @@ void batcher_loop()
     for (;;) {
         b.work_cv.wait(lk, [&] { return b.stop || !b.queue.empty(); });
         if (b.stop && b.queue.empty()) return;
-        // hold the door open for a short window so that callers arriving together share a launch
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b.window_us);
-        while (!b.stop && b.queued_bytes < b.max_bytes &&
-               b.work_cv.wait_until(lk, deadline) != std::cv_status::timeout) {
+        // With window 0 a batch is whatever queued up while the previous one was
+        // on the device (no added latency); a window > 0 also holds the door
+        // open that long for callers arriving together.
+        if (b.window_us > 0) {
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b.window_us);
+            while (!b.stop && b.queued_bytes < b.max_bytes &&
+                   b.work_cv.wait_until(lk, deadline) != std::cv_status::timeout) {
+            }
         }
         std::vector<Job*> batch;
         batch.swap(b.queue);
@@ -407,7 +412,7 @@ void SetMicroBatching(bool enable, int windowMicros, size_t maxBytes)
 {
     Batcher& b = g_batcher;
     std::unique_lock<std::mutex> lk(b.mu);
-    if (windowMicros > 0) b.window_us = windowMicros;
+    if (windowMicros >= 0) b.window_us = windowMicros;
     if (maxBytes > 0) b.max_bytes = maxBytes;
     if (enable && !b.enabled) {
         b.stop = false;
@@ -432,7 +437,7 @@ void MicroBatchingStats(uint64_t* batches, uint64_t* jobs)
 
 void Shutdown()
 {
-    SetMicroBatching(false, 0, 0);
+    SetMicroBatching(false, -1, 0);
     Engine& e = g_engine;
     std::lock_guard<std::mutex> lk(e.mu);
     if (!e.ctx) return;
@@ -728,22 +733,84 @@ Error ValidBytes(int64_t workerID, const std::string& expectedBucketName, const 
     return finish_valid(workerID, obj, body, st, job);
 }
 
+namespace {
+
+// Validates units [firstUnit, firstUnit + n) of an object, held in `data`;
+// returns the reference's error for the first bad one, or nil.
+Error validate_span(int64_t workerID, const std::string& bucket16, const object::Object* obj,
+                    uint32_t firstUnit, const uint8_t* data, uint32_t n)
+{
+    Job job;
+    job.is_fill = false;
+    job.in = data;
+    bool ok = false;
+    const uint32_t forced = validation_desc(bucket16, obj, workerID, firstUnit, n, &job.desc, &ok);
+    if (!ok) return Error::New(std::string("oval engine failure: ") + oval_last_error());
+    execute(job);
+    if (job.failed) return engine_error(g_engine);
+    if (forced) {
+        // a name longer than its field fails in the span's very first unit
+        uint32_t mask = forced;
+        if (job.res.first_bad_unit == firstUnit) mask |= job.res.first_bad_fields;
+        return Error::New(unit_error_text(mask, firstUnit, workerID, bucket16, obj, data));
+    }
+    if (job.res.first_bad_unit != OVAL_NO_BAD_UNIT) {
+        const uint8_t* unit = data + (size_t)(job.res.first_bad_unit - firstUnit) * dataUnitSize;
+        return Error::New(unit_error_text(job.res.first_bad_fields, job.res.first_bad_unit, workerID, bucket16,
+                                          obj, unit));
+    }
+    return Error::Nil();
+}
+
+size_t g_stream_chunk_bytes = 32u << 20;
+
+}  // namespace
+
+void SetStreamChunkBytes(size_t bytes)
+{
+    if (bytes < (size_t)dataUnitSize) bytes = dataUnitSize;
+    g_stream_chunk_bytes = bytes - bytes % dataUnitSize;
+}
+
+// The body is consumed in chunks of at most SetStreamChunkBytes() (32 MiB by
+// default) so that a multipart-sized object needs neither a body-sized host
+// buffer nor a body-sized device buffer.  Reading stops at the first chunk
+// that holds a bad unit, as the reference stops at the first bad unit.
 Error Valid(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
             Reader& reader)
 {
+    const std::string bucket16 = truncate_bucket(expectedBucketName);
     const int64_t nUnits = obj->Size / dataUnitSize;
-    if (nUnits <= 0) return Error::Nil();
+    if (nUnits <= 0) return Error::Nil();                    // the loop at :123 does not run
     if (nUnits > 0xFFFFFFF0ll) return Error::New("object size beyond the engine's 1 TiB limit");
-    const size_t want = (size_t)nUnits * dataUnitSize;
-    // io.ReadFull unit by unit (:124) == read until `want` bytes or EOF
-    std::vector<uint8_t> body(want);
-    size_t avail = 0;
-    while (avail < want) {
-        const size_t n = reader.Read(body.data() + avail, want - avail);
-        if (n == 0) break;
-        avail += n;
+    const size_t chunk_units = g_stream_chunk_bytes / dataUnitSize;
+    std::vector<uint8_t> buf((size_t)std::min<int64_t>(nUnits, (int64_t)chunk_units) * dataUnitSize);
+    int64_t done = 0;
+    while (done < nUnits) {
+        const size_t want = (size_t)std::min<int64_t>(nUnits - done, (int64_t)chunk_units) * dataUnitSize;
+        // io.ReadFull unit by unit (:124) == read until `want` bytes or EOF
+        size_t got = 0;
+        while (got < want) {
+            const size_t n = reader.Read(buf.data() + got, want - got);
+            if (n == 0) break;
+            got += n;
+        }
+        const size_t complete = got / dataUnitSize;
+        if (complete > 0) {
+            Error err = validate_span(workerID, bucket16, obj, (uint32_t)done, buf.data(), (uint32_t)complete);
+            if (!err.nil()) return err;                      // :128-131 a bad unit wins over a later short read
+        }
+        if (got < want) {
+            // :125-127 the unit that could not be read in full
+            const size_t n = got - complete * dataUnitSize;
+            char head[96];
+            std::snprintf(head, sizeof head, "could not read some data. (expected: %dbyte, actual: %zubyte)\n",
+                          dataUnitSize, n);
+            return Error::New(std::string(head) + dump(hexDump(buf.data() + complete * dataUnitSize, n)));
+        }
+        done += (int64_t)complete;
     }
-    return ValidBytes(workerID, expectedBucketName, obj, body.data(), avail);
+    return Error::Nil();
 }
 
 std::vector<Error> ValidBatch(const std::vector<ValidItem>& items)
@@ -935,6 +1002,29 @@ int oval_pattern_valid_data_unit(int64_t unit_count, int64_t worker_id, const ch
     const std::string b(bucket ? bucket : "", bucket_len);
     return put_error(oval::pattern::validDataUnit(unit_count, worker_id, b, &obj, data), err, err_cap);
 }
+
+namespace {
+class CallbackReader : public oval::pattern::Reader {
+public:
+    CallbackReader(oval_read_fn fn, void* user) : fn_(fn), user_(user) {}
+    size_t Read(uint8_t* p, size_t n) override { return fn_ ? fn_(user_, p, n) : 0; }
+private:
+    oval_read_fn fn_;
+    void* user_;
+};
+}  // namespace
+
+int oval_pattern_valid_stream(int64_t worker_id, const char* bucket, size_t bucket_len, const char* key,
+                              size_t key_len, int64_t size, int64_t write_count, oval_read_fn read, void* user,
+                              char* err, size_t err_cap)
+{
+    const oval::object::Object obj = make_obj(key, key_len, size, write_count);
+    const std::string b(bucket ? bucket : "", bucket_len);
+    CallbackReader rd(read, user);
+    return put_error(oval::pattern::Valid(worker_id, b, &obj, rd), err, err_cap);
+}
+
+void oval_pattern_set_stream_chunk(size_t bytes) { oval::pattern::SetStreamChunkBytes(bytes); }
 
 void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes)
 {

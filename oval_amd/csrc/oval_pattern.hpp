@@ -128,9 +128,13 @@ void Seed(uint64_t seed);           // source of rand.Float64() in DecideSize
 const std::string& LastEngineError();
 // Micro-batching: while enabled, concurrent Generate / Valid calls (one per
 // worker thread, internal/runner/runner.go:186-214) that arrive within
-// `windowMicros` of each other share one device launch.  Results are identical.
-void SetMicroBatching(bool enable, int windowMicros = 100, size_t maxBytes = 64u << 20);
+// `windowMicros` of each other share one device launch; with window 0 a batch is
+// whatever queued up while the previous batch was on the device.  Results are
+// identical either way.  A negative window keeps the current setting.
+void SetMicroBatching(bool enable, int windowMicros = 0, size_t maxBytes = 64u << 20);
 void MicroBatchingStats(uint64_t* batches, uint64_t* jobs);
+// Valid(reader) consumes the body in chunks of at most this many bytes.
+void SetStreamChunkBytes(size_t bytes);
 
 }  // namespace pattern
 }  // namespace oval

@@ -99,6 +99,32 @@ def Valid(workerID: int, expectedBucketName, obj: Object, reader) -> None:
     _raise(rc, err)
 
 
+_READ_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+
+
+def ValidStream(workerID: int, expectedBucketName, obj: Object, reader) -> None:
+    """pattern.go:118-134 with a file-like reader (`reader.read(n)` returns up
+    to n bytes, b"" at EOF); the body is validated chunk by chunk."""
+    b, k = _b(expectedBucketName), _b(obj.Key)
+
+    def cb(_user, p, n):
+        data = reader.read(n)
+        if not data:
+            return 0
+        C.memmove(p, data, len(data))
+        return len(data)
+
+    fn = _READ_FN(cb)
+    err = C.create_string_buffer(_ERR_CAP)
+    rc = _lib.lib().oval_pattern_valid_stream(workerID, b, len(b), k, len(k), obj.Size, obj.WriteCount,
+                                              C.cast(fn, C.c_void_p), None, err, _ERR_CAP)
+    _raise(rc, err)
+
+
+def set_stream_chunk(nbytes: int) -> None:
+    _lib.lib().oval_pattern_set_stream_chunk(nbytes)
+
+
 def validDataUnit(unitCount: int, workerID: int, expectedBucketName, obj: Object, data) -> None:
     """pattern.go:136-180"""
     b, k, d = _b(expectedBucketName), _b(obj.Key), _b(data)
@@ -111,7 +137,7 @@ def validDataUnit(unitCount: int, workerID: int, expectedBucketName, obj: Object
     _raise(rc, err)
 
 
-def set_batching(enable: bool, window_us: int = 100, max_bytes: int = 64 << 20) -> None:
+def set_batching(enable: bool, window_us: int = 0, max_bytes: int = 64 << 20) -> None:
     """Coalesce concurrent Generate / Valid calls from different threads into
     shared device launches (results are unchanged)."""
     _lib.lib().oval_pattern_set_batching(1 if enable else 0, window_us, max_bytes)
