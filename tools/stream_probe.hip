@@ -189,6 +189,41 @@ __global__ __launch_bounds__(256) void write_burst_kernel(u32x4* __restrict__ bu
     }
 }
 
+// Persistent workgroups of 1024 threads, one per CU: each owns a contiguous
+// share of the buffer and alternates between loading a table slice into LDS in
+// one burst (BURST_KIB) and writing the matching stretch of the buffer with no
+// reads at all.  The read volume per byte written is the same as above.
+template <int BURST_KIB>
+__global__ __launch_bounds__(1024) void write_phased_kernel(u32x4* __restrict__ buf, uint32_t n_tiles,
+                                                            const u32x4* __restrict__ table, uint32_t table_kib)
+{
+    __shared__ u32x4 lds[BURST_KIB * 64];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;                      // 16 waves
+    const uint32_t tiles_per_block = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t t_begin = blockIdx.x * tiles_per_block;
+    const uint32_t t_end = min(n_tiles, t_begin + tiles_per_block);
+    const uint32_t tiles_per_round = BURST_KIB * 2;              // 64 B of table per 8 KiB written
+    u32x4 v = {(uint32_t)lane, 1u, 2u, 3u};
+    uint32_t round = 0;
+    for (uint32_t r0 = t_begin; r0 < t_end; r0 += tiles_per_round, ++round) {
+        const uint32_t base = ((blockIdx.x + round * gridDim.x) * BURST_KIB) % (table_kib - BURST_KIB);
+        for (uint32_t i = threadIdx.x; i < BURST_KIB * 64; i += 1024)
+            lds[i] = __builtin_nontemporal_load(&table[(size_t)base * 64 + i]);
+        __syncthreads();
+        v.y += lds[(lane * 17 + wave) % (BURST_KIB * 64)].x;
+        const uint32_t r1 = min(t_end, r0 + tiles_per_round);
+        for (uint32_t t = r0 + wave; t < r1; t += 16) {
+#pragma unroll 8
+            for (int k = 0; k < 64; ++k) {
+                v.x += 256u;
+                buf[((size_t)t * 64 + k) * 64 + lane] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 struct Result { const char* name; double best_gbs, med_gbs; };
 
 template <class F>
@@ -277,6 +312,17 @@ int main(int argc, char** argv)
             time_it(name, bytes, [&] { write_burst_kernel<L><<<grid, 256>>>(buf, n_tiles, table, n_entries / 16); });
             WB(1) WB(4) WB(16)
 #undef WB
+        }
+        for (int bpc : {1, 2}) {
+            const int grid = cus * bpc;
+            if (bpc == 1) {
+                snprintf(name, sizeof name, "write phased, 128 KiB LDS burst, 1024 thr, %d b/CU", bpc);
+                time_it(name, bytes, [&] { write_phased_kernel<128><<<grid, 1024>>>(buf, n_tiles, table, n_entries / 16); });
+            }
+            snprintf(name, sizeof name, "write phased,  64 KiB LDS burst, 1024 thr, %d b/CU", bpc);
+            time_it(name, bytes, [&] { write_phased_kernel<64><<<grid, 1024>>>(buf, n_tiles, table, n_entries / 16); });
+            snprintf(name, sizeof name, "write phased,  16 KiB LDS burst, 1024 thr, %d b/CU", bpc);
+            time_it(name, bytes, [&] { write_phased_kernel<16><<<grid, 1024>>>(buf, n_tiles, table, n_entries / 16); });
         }
         // a table small enough to stay in every XCD's L2
         for (int bpc : {4, 8}) {
