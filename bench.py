@@ -185,11 +185,10 @@ def main():
         value = 512.0 * units_all / (wall / args.steps) / 1e9
         fill_gbs = 256.0 * units / (fill_ms / 1e3) / 1e9
         val_gbs = 256.0 * units / (val_ms / 1e3) / 1e9
-        # kernel names as rocprofv3 reports them; the library picks the fill family by mean object size
-        auto = args.variant < 0
-        wave = (units // max(n_obj, 1) >= 128) if auto else not (args.variant & 4)
-        fill_name = "fill_wave_kernel<4>" if wave else "fill_kernel<4>"
-        val_name = "validate_kernel<4>" if auto or (args.variant & 4) else "validate_wave_kernel<8>"
+        # kernel names as rocprofv3 reports them
+        shape = {0: ("<4, 1>", "<4, 1>"), 1: ("<8, 1>", "<8, 1>"), 2: ("<4, 2>", "<4, 2>"), 3: ("<4, 4>", "<2, 1>")}[
+            (max(args.variant, 0) >> 4) & 3]
+        fill_name, val_name = "fill_kernel" + shape[0], "validate_kernel" + shape[1]
         dom, dom_ms, dom_gbs = (val_name, val_ms, val_gbs) if val_ms >= fill_ms else (fill_name, fill_ms, fill_gbs)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -166,7 +166,7 @@ int oval_desc_init(oval_obj_desc* d,
                    uint64_t body_offset, uint32_t first_unit, uint32_t n_units);
 
 /* ---- layout -------------------------------------------------------------
- * Uploads `n_obj` descriptors and builds the device-side chunk index.
+ * Uploads `n_obj` descriptors and builds the device-side tile index.
  * Requirements (checked; OVAL_E_LAYOUT otherwise): body_offset is a multiple
  * of 256 and bodies are in ascending, non-overlapping order (gaps and
  * zero-unit objects are allowed).  The layout can be used for any number of
@@ -214,10 +214,10 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs_host, uin
                              oval_obj_result* results_host, uint64_t* counters_host);
 
 /* ---- kernel launch tuning (benchmarks only) ------------------------------
- * By default the library picks the kernel family and grid per launch from the
- * batch shape.  blocks_per_cu > 0 and/or variant >= 0 pin them (variant bit 0:
- * XCD-contiguous tile order, bit 2: group-walk kernels, bits 4-5: unroll);
- * blocks_per_cu <= 0 / variant < 0 restore the automatic choice. */
+ * blocks_per_cu > 0 sets the grid (workgroups of 256 threads per CU); variant
+ * >= 0 selects a kernel shape (bit 0: XCD-contiguous tile order, bits 4-5:
+ * unroll / tiles per wavefront pass).  blocks_per_cu <= 0 / variant < 0 restore
+ * the defaults. */
 int oval_ctx_set_tuning(oval_ctx* ctx, int blocks_per_cu, int variant);
 
 /* ---- timing --------------------------------------------------------------

@@ -43,14 +43,14 @@ struct oval_ctx {
 struct oval_layout {
     int       device = 0;
     void*     descs_dev = nullptr;
-    uint32_t* chunk_first_dev = nullptr;
+    uint32_t* tile_first_dev = nullptr;
     uint64_t  n_obj = 0;
     uint64_t  total_units = 0;
     uint64_t  span_bytes = 0;
-    uint32_t  n_chunks = 0;
+    uint32_t  n_tiles = 0;
     bool      no_fill = false;   // some descriptor carries OVAL_DESC_NO_FILL
     uint64_t  cap_obj = 0;       // descriptors the device table can hold
-    uint32_t  cap_chunks = 0;    // entries the chunk table can hold
+    uint32_t  cap_tiles = 0;    // entries the tile table can hold
 };
 
 struct oval_timer {
@@ -84,35 +84,29 @@ oval::LayoutView view_of(const oval_layout* l)
 {
     oval::LayoutView v;
     v.descs = l->descs_dev;
-    v.chunk_first = l->chunk_first_dev;
+    v.tile_first = l->tile_first_dev;
     v.n_obj = (uint32_t)l->n_obj;
-    v.n_chunks = l->n_chunks;
+    v.n_tiles = l->n_tiles;
     v.span_units = (uint32_t)(l->span_bytes / OVAL_UNIT_SIZE);
     v.total_units = l->total_units;
     return v;
 }
 
-// Launch shape.  Measured on MI355X (tools/sweep2.sh): the group-walk kernels
-// (variant 4) are fastest for validation at 4 workgroups per CU whatever the
-// object size, and for filling small objects at 2 per CU; the wave-walk fill
-// (variant 0) wins once objects average 32 KiB or more.  An explicit
-// oval_ctx_set_tuning() overrides either choice.
-oval::LaunchCfg cfg_of(const oval_ctx* c, const oval_layout* l, bool is_fill)
+// Launch shape.  Measured on MI355X (tools/sweep.sh): 4 workgroups of 256
+// threads per CU is the best grid for both kernels at every object size tried
+// (4 KiB ... 256 MiB); more wavefronts put too many bytes in flight and cost the
+// validate kernel up to 12 %.  oval_ctx_set_tuning() overrides it.
+oval::LaunchCfg cfg_of(const oval_ctx* c, const oval_layout*, bool)
 {
-    const uint64_t mean_units = l->n_obj ? l->total_units / l->n_obj : 0;
-    int variant = c->variant;
-    int bpc = c->blocks_per_cu;
-    if (variant < 0) variant = (is_fill && mean_units >= 128) ? 0 : 4;
-    if (bpc <= 0) bpc = is_fill ? ((variant & 4) ? 2 : 4) : 4;
     oval::LaunchCfg k;
-    k.grid_blocks = c->n_cu * bpc;
-    k.variant = variant;
+    k.grid_blocks = c->n_cu * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 4);
+    k.variant = c->variant < 0 ? 0 : c->variant;
     return k;
 }
 
 uint32_t tiles_of(const oval_layout* l)
 {
-    return (l->n_chunks + oval::kChunksPerTile - 1) / oval::kChunksPerTile;
+    return l->n_tiles;
 }
 
 // true when strings.TrimSpace(name) != name, i.e. the expected name itself
@@ -343,7 +337,7 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
     int rc = scan_descs(descs, n_obj, &total_units, &span_bytes, &no_fill);
     if (rc) return rc;
     const uint64_t span_units = span_bytes / OVAL_UNIT_SIZE;
-    const uint32_t n_chunks = (uint32_t)((span_units + oval::kUnitsPerChunk - 1) / oval::kUnitsPerChunk);
+    const uint32_t n_tiles = (uint32_t)((span_units + oval::kUnitsPerTile - 1) / oval::kUnitsPerTile);
     HIP_TRY(hipSetDevice(ctx->device));
     // a pass that still uses the old tables must finish before they are replaced
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -353,20 +347,20 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
         HIP_TRY(hipMalloc(&l->descs_dev, cap * sizeof(oval_obj_desc)));
         l->cap_obj = cap;
     }
-    if (n_chunks > l->cap_chunks || !l->chunk_first_dev) {
-        if (l->chunk_first_dev) { (void)hipFree(l->chunk_first_dev); l->chunk_first_dev = nullptr; l->cap_chunks = 0; }
-        const uint32_t cap = n_chunks ? n_chunks : 1;
-        HIP_TRY(hipMalloc((void**)&l->chunk_first_dev, (size_t)cap * 4));
-        l->cap_chunks = cap;
+    if (n_tiles > l->cap_tiles || !l->tile_first_dev) {
+        if (l->tile_first_dev) { (void)hipFree(l->tile_first_dev); l->tile_first_dev = nullptr; l->cap_tiles = 0; }
+        const uint32_t cap = n_tiles ? n_tiles : 1;
+        HIP_TRY(hipMalloc((void**)&l->tile_first_dev, (size_t)cap * 4));
+        l->cap_tiles = cap;
     }
     l->n_obj = n_obj;
     l->no_fill = no_fill;
     l->total_units = total_units;
     l->span_bytes = span_bytes;
-    l->n_chunks = n_chunks;
+    l->n_tiles = n_tiles;
     if (n_obj)
         HIP_TRY(hipMemcpyAsync(l->descs_dev, descs, n_obj * sizeof(oval_obj_desc), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(oval::launch_build_chunk_table(ctx->stream, l->descs_dev, (uint32_t)n_obj, l->chunk_first_dev, n_chunks));
+    HIP_TRY(oval::launch_build_tile_table(ctx->stream, l->descs_dev, (uint32_t)n_obj, l->tile_first_dev, n_tiles));
     // the caller's descriptor array may be pageable and is not retained: wait for the upload
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return OVAL_OK;
@@ -382,7 +376,7 @@ int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj
     int rc = oval_layout_reset(ctx, l, descs, n_obj);
     if (rc) {
         if (l->descs_dev) (void)hipFree(l->descs_dev);
-        if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
+        if (l->tile_first_dev) (void)hipFree(l->tile_first_dev);
         delete l;
         return rc;
     }
@@ -395,7 +389,7 @@ int oval_layout_destroy(oval_ctx* ctx, oval_layout* l)
     if (!l) return OVAL_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     if (l->descs_dev) (void)hipFree(l->descs_dev);
-    if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
+    if (l->tile_first_dev) (void)hipFree(l->tile_first_dev);
     delete l;
     return OVAL_OK;
 }
@@ -462,7 +456,7 @@ int oval_read_unit(oval_ctx* ctx, const void* body_dev, uint64_t byte_offset, ui
 // on the main stream while the copy of slice k-1 (fill) or k+1 (validate) runs
 // on the copy stream.
 namespace {
-constexpr uint64_t kTileBytes = (uint64_t)oval::kUnitsPerChunk * oval::kChunksPerTile * OVAL_UNIT_SIZE;
+constexpr uint64_t kTileBytes = (uint64_t)oval::kUnitsPerTile * OVAL_UNIT_SIZE;
 constexpr uint32_t kSliceTiles = 512;   // 32 MiB
 }
 
