@@ -100,8 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--objects", type=int, default=0, help="objects per GPU (default: the workload's)")
-    ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--fill-threads", type=int, default=0, help="workgroup size of the fill kernel (0 = default)")
+    ap.add_argument("--validate-threads", type=int, default=0, help="workgroup size of the validate kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--sizes", default="", help="override object sizes, e.g. 65536-65536 (bytes, multiples of 256)")
@@ -131,7 +131,7 @@ def main():
     stream = torch.cuda.Stream(local)
     torch.cuda.set_stream(stream)
     ctx = engine.Context(local, stream.cuda_stream)
-    ctx.set_tuning(args.blocks_per_cu, args.variant)
+    ctx.set_tuning(args.fill_threads, args.validate_threads)
 
     size_override = tuple(int(x) for x in args.sizes.split("-")) if args.sizes else None
     descs = build_batch(args.workload, rank, args.objects, args.seed, size_override)
@@ -186,9 +186,8 @@ def main():
         fill_gbs = 256.0 * units / (fill_ms / 1e3) / 1e9
         val_gbs = 256.0 * units / (val_ms / 1e3) / 1e9
         # kernel names as rocprofv3 reports them
-        shape = {0: ("<4, 1>", "<4, 1>"), 1: ("<8, 1>", "<8, 1>"), 2: ("<4, 2>", "<4, 2>"), 3: ("<4, 4>", "<2, 1>")}[
-            (max(args.variant, 0) >> 4) & 3]
-        fill_name, val_name = "fill_kernel" + shape[0], "validate_kernel" + shape[1]
+        fill_name = "fill_kernel<%d>" % (args.fill_threads or 256)
+        val_name = "validate_kernel<%d>" % (args.validate_threads or 256)
         dom, dom_ms, dom_gbs = (val_name, val_ms, val_gbs) if val_ms >= fill_ms else (fill_name, fill_ms, fill_gbs)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -204,7 +203,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][4]}", "objects_per_gpu": n_obj,
                        "units_per_gpu": units, "bytes_per_gpu": nbytes, "sharding": "worker key range (process ID = rank)",
-                       "blocks_per_cu": args.blocks_per_cu or "auto", "variant": args.variant if args.variant >= 0 else "auto"},
+                       "fill_threads": args.fill_threads or 256, "validate_threads": args.validate_threads or 256},
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,

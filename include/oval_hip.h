@@ -214,11 +214,9 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs_host, uin
                              oval_obj_result* results_host, uint64_t* counters_host);
 
 /* ---- kernel launch tuning (benchmarks only) ------------------------------
- * blocks_per_cu > 0 sets the grid (workgroups of 256 threads per CU); variant
- * >= 0 selects a kernel shape (bit 0: XCD-contiguous tile order, bits 4-5:
- * unroll / tiles per wavefront pass).  blocks_per_cu <= 0 / variant < 0 restore
- * the defaults. */
-int oval_ctx_set_tuning(oval_ctx* ctx, int blocks_per_cu, int variant);
+ * Workgroup sizes of the fill and the validate kernel: 128, 256, 512 or 1024
+ * threads; 0 restores the default (256, the fastest measured for both). */
+int oval_ctx_set_tuning(oval_ctx* ctx, int fill_threads, int validate_threads);
 
 /* ---- timing --------------------------------------------------------------
  * HIP events recorded on the context's stream, for callers (bench.py) that

@@ -36,14 +36,15 @@ struct oval_ctx {
     bool        own_stream  = false;
     hipStream_t copy_stream = nullptr;   // second stream for overlapped host copies
     int         n_cu        = 256;
-    int         blocks_per_cu = 0;     // 0: chosen per kernel and batch shape
-    int         variant     = -1;      // -1: chosen per kernel and batch shape
+    int         fill_threads = 256;    // workgroup sizes of the two kernels
+    int         validate_threads = 256;
+    unsigned long long* tallies_dev = nullptr;   // striped bad-unit tallies of the validate kernels, zero between passes
 };
 
 struct oval_layout {
     int       device = 0;
     void*     descs_dev = nullptr;
-    uint32_t* tile_first_dev = nullptr;
+    uint32_t* chunk_first_dev = nullptr;
     uint64_t  n_obj = 0;
     uint64_t  total_units = 0;
     uint64_t  span_bytes = 0;
@@ -84,7 +85,7 @@ oval::LayoutView view_of(const oval_layout* l)
 {
     oval::LayoutView v;
     v.descs = l->descs_dev;
-    v.tile_first = l->tile_first_dev;
+    v.chunk_first = l->chunk_first_dev;
     v.n_obj = (uint32_t)l->n_obj;
     v.n_tiles = l->n_tiles;
     v.span_units = (uint32_t)(l->span_bytes / OVAL_UNIT_SIZE);
@@ -92,15 +93,14 @@ oval::LayoutView view_of(const oval_layout* l)
     return v;
 }
 
-// Launch shape.  Measured on MI355X (tools/sweep.sh): 4 workgroups of 256
-// threads per CU is the best grid for both kernels at every object size tried
-// (4 KiB ... 256 MiB); more wavefronts put too many bytes in flight and cost the
-// validate kernel up to 12 %.  oval_ctx_set_tuning() overrides it.
-oval::LaunchCfg cfg_of(const oval_ctx* c, const oval_layout*, bool)
+// Launch shape: workgroups of 256 threads measured best for both kernels
+// (128 / 512 / 1024: fill -15 / -1 / -10 %, validate -2 / 0 / -7 %);
+// oval_ctx_set_tuning() overrides it for such sweeps.
+oval::LaunchCfg cfg_of(const oval_ctx* c)
 {
     oval::LaunchCfg k;
-    k.grid_blocks = c->n_cu * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 4);
-    k.variant = c->variant < 0 ? 0 : c->variant;
+    k.fill_threads = c->fill_threads;
+    k.validate_threads = c->validate_threads;
     return k;
 }
 
@@ -166,6 +166,15 @@ int oval_ctx_create(int device_id, void* stream, oval_ctx** out)
         delete c;
         return fail(OVAL_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    e = hipMalloc((void**)&c->tallies_dev, oval::kTallyBytes);
+    if (e == hipSuccess) e = hipMemset(c->tallies_dev, 0, oval::kTallyBytes);
+    if (e != hipSuccess) {
+        if (c->tallies_dev) (void)hipFree(c->tallies_dev);
+        (void)hipStreamDestroy(c->copy_stream);
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(OVAL_E_NOMEM, "hipMalloc(tallies): %s", hipGetErrorString(e));
+    }
     *out = c;
     return OVAL_OK;
 }
@@ -178,6 +187,7 @@ int oval_ctx_destroy(oval_ctx* ctx)
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->tallies_dev) (void)hipFree(ctx->tallies_dev);
     delete ctx;
     return OVAL_OK;
 }
@@ -196,11 +206,14 @@ int oval_ctx_stream(oval_ctx* ctx, void** stream_out)
     return OVAL_OK;
 }
 
-int oval_ctx_set_tuning(oval_ctx* ctx, int blocks_per_cu, int variant)
+int oval_ctx_set_tuning(oval_ctx* ctx, int fill_threads, int validate_threads)
 {
     if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
-    ctx->blocks_per_cu = blocks_per_cu > 0 ? (blocks_per_cu > 64 ? 64 : blocks_per_cu) : 0;
-    ctx->variant = variant < 0 ? -1 : variant;
+    auto ok = [](int t) { return t <= 0 || t == 128 || t == 256 || t == 512 || t == 1024; };
+    if (!ok(fill_threads) || !ok(validate_threads))
+        return fail(OVAL_E_INVALID, "workgroup sizes are 128, 256, 512 or 1024 threads (0 = default)");
+    ctx->fill_threads = fill_threads > 0 ? fill_threads : 256;
+    ctx->validate_threads = validate_threads > 0 ? validate_threads : 256;
     return OVAL_OK;
 }
 
@@ -347,10 +360,10 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
         HIP_TRY(hipMalloc(&l->descs_dev, cap * sizeof(oval_obj_desc)));
         l->cap_obj = cap;
     }
-    if (n_tiles > l->cap_tiles || !l->tile_first_dev) {
-        if (l->tile_first_dev) { (void)hipFree(l->tile_first_dev); l->tile_first_dev = nullptr; l->cap_tiles = 0; }
+    if (n_tiles > l->cap_tiles || !l->chunk_first_dev) {
+        if (l->chunk_first_dev) { (void)hipFree(l->chunk_first_dev); l->chunk_first_dev = nullptr; l->cap_tiles = 0; }
         const uint32_t cap = n_tiles ? n_tiles : 1;
-        HIP_TRY(hipMalloc((void**)&l->tile_first_dev, (size_t)cap * 4));
+        HIP_TRY(hipMalloc((void**)&l->chunk_first_dev, (size_t)cap * oval::kChunksPerTile * 4));
         l->cap_tiles = cap;
     }
     l->n_obj = n_obj;
@@ -360,7 +373,7 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
     l->n_tiles = n_tiles;
     if (n_obj)
         HIP_TRY(hipMemcpyAsync(l->descs_dev, descs, n_obj * sizeof(oval_obj_desc), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(oval::launch_build_tile_table(ctx->stream, l->descs_dev, (uint32_t)n_obj, l->tile_first_dev, n_tiles));
+    HIP_TRY(oval::launch_build_chunk_table(ctx->stream, l->descs_dev, (uint32_t)n_obj, l->chunk_first_dev, n_tiles));
     // the caller's descriptor array may be pageable and is not retained: wait for the upload
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return OVAL_OK;
@@ -376,7 +389,7 @@ int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj
     int rc = oval_layout_reset(ctx, l, descs, n_obj);
     if (rc) {
         if (l->descs_dev) (void)hipFree(l->descs_dev);
-        if (l->tile_first_dev) (void)hipFree(l->tile_first_dev);
+        if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
         delete l;
         return rc;
     }
@@ -389,7 +402,7 @@ int oval_layout_destroy(oval_ctx* ctx, oval_layout* l)
     if (!l) return OVAL_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     if (l->descs_dev) (void)hipFree(l->descs_dev);
-    if (l->tile_first_dev) (void)hipFree(l->tile_first_dev);
+    if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
     delete l;
     return OVAL_OK;
 }
@@ -422,7 +435,7 @@ int oval_fill(oval_ctx* ctx, const oval_layout* l, void* body_dev, uint64_t body
     if (l->no_fill)
         return fail(OVAL_E_FIELD, "the layout holds an object whose names do not format to 28 bytes; "
                                   "the reference's Generate fails for it (pattern.go:87-89)");
-    HIP_TRY(oval::launch_fill(ctx->stream, cfg_of(ctx, l, true), view_of(l), body_dev, 0, tiles_of(l)));
+    HIP_TRY(oval::launch_fill(ctx->stream, cfg_of(ctx), view_of(l), body_dev, 0, tiles_of(l)));
     return OVAL_OK;
 }
 
@@ -436,8 +449,8 @@ int oval_validate(oval_ctx* ctx, const oval_layout* l, const void* body_dev, uin
     if (((uintptr_t)counters_dev) % 8) return fail(OVAL_E_INVALID, "counters_dev is not 8-byte aligned");
     const oval::LayoutView v = view_of(l);
     HIP_TRY(oval::launch_init_results(ctx->stream, v, results_dev, (unsigned long long*)counters_dev));
-    HIP_TRY(oval::launch_validate(ctx->stream, cfg_of(ctx, l, false), v, body_dev, 0, tiles_of(l), results_dev,
-                                  (unsigned long long*)counters_dev));
+    HIP_TRY(oval::launch_validate(ctx->stream, cfg_of(ctx), v, body_dev, 0, tiles_of(l), results_dev,
+                                  (unsigned long long*)counters_dev, ctx->tallies_dev));
     return OVAL_OK;
 }
 
@@ -481,7 +494,7 @@ int oval_fill_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_o
     uint32_t k = 0;
     for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles, ++k) {
         const uint32_t t1 = t0 + kSliceTiles < n_tiles ? t0 + kSliceTiles : n_tiles;
-        e = oval::launch_fill(ctx->stream, cfg_of(ctx, l, true), v, dev, t0, t1);
+        e = oval::launch_fill(ctx->stream, cfg_of(ctx), v, dev, t0, t1);
         if (e == hipSuccess) e = hipEventRecord(ev[k & 1], ctx->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ev[k & 1], 0);
         const uint64_t b0 = (uint64_t)t0 * kTileBytes;
@@ -538,7 +551,8 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
                                ctx->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(ev, ctx->copy_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
-        if (e == hipSuccess) e = oval::launch_validate(ctx->stream, cfg_of(ctx, l, false), v, dev, t0, t1, res_dev, cnt_dev);
+        if (e == hipSuccess) e = oval::launch_validate(ctx->stream, cfg_of(ctx), v, dev, t0, t1, res_dev, cnt_dev,
+                                                       ctx->tallies_dev);
     }
     if (e == hipSuccess && n_obj)
         e = hipMemcpyAsync(results_host, res_dev, n_obj * sizeof(oval_obj_result), hipMemcpyDeviceToHost, ctx->stream);

@@ -8,14 +8,23 @@
 
 namespace oval {
 
-// One wavefront instruction covers 4 consecutive units (1 KiB); a tile is the
-// granularity of the tile table and of host-staging slices.
-constexpr uint32_t kUnitsPerTile  = 256;                   // 64 KiB
-constexpr uint32_t kBlockThreads  = 256;                   // 4 wavefronts
+// One wavefront instruction covers 4 consecutive units (1 KiB).  A chunk is the
+// granularity of the object lookup table and what one fill workgroup writes; a
+// tile is what a validating wavefront takes per pass and the unit of
+// host-staging slices.
+constexpr uint32_t kUnitsPerChunk = 16;                    // 4 KiB
+constexpr uint32_t kChunksPerTile = 16;
+constexpr uint32_t kUnitsPerTile  = kUnitsPerChunk * kChunksPerTile;   // 64 KiB
+
+// Bad-unit tallies are spread over this many copies of the counter vector, one
+// 128-byte line each, and folded into the caller's counters after the pass.
+constexpr uint32_t kTallyStripes = 256;
+constexpr uint32_t kTallyStride  = 16;                     // u64 per stripe
+constexpr size_t   kTallyBytes   = (size_t)kTallyStripes * kTallyStride * 8;
 
 struct LayoutView {
     const void*     descs;        // oval_obj_desc[n_obj] in device memory
-    const uint32_t* tile_first;   // [n_tiles] first object whose end lies beyond the tile's first unit
+    const uint32_t* chunk_first;  // [n_tiles * kChunksPerTile] first object whose end lies beyond the chunk's first unit
     uint32_t        n_obj;
     uint32_t        n_tiles;
     uint32_t        span_units;   // units from offset 0 to the end of the last object
@@ -23,18 +32,19 @@ struct LayoutView {
 };
 
 struct LaunchCfg {
-    int grid_blocks;   // number of 256-thread workgroups
-    int variant;       // bit 0: XCD-contiguous tile order; bits 4-5: unroll / tiles per pass (benchmarks)
+    int fill_threads;       // workgroup size of the fill kernel: 128, 256 (shipped), 512, 1024
+    int validate_threads;   // workgroup size of the validate kernel, likewise
 };
 
-hipError_t launch_build_tile_table(hipStream_t s, const void* descs, uint32_t n_obj,
-                                   uint32_t* tile_first, uint32_t n_tiles);
+hipError_t launch_build_chunk_table(hipStream_t s, const void* descs, uint32_t n_obj,
+                                    uint32_t* chunk_first, uint32_t n_tiles);
 hipError_t launch_fill(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv, void* body,
                        uint32_t tile_begin, uint32_t tile_end);
 hipError_t launch_init_results(hipStream_t s, const LayoutView& lv, oval_obj_result* results,
                                unsigned long long* counters);
 hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv,
                            const void* body, uint32_t tile_begin, uint32_t tile_end,
-                           oval_obj_result* results, unsigned long long* counters);
+                           oval_obj_result* results, unsigned long long* counters,
+                           unsigned long long* stripes);
 
 }  // namespace oval

@@ -12,11 +12,18 @@
 // registers, lanes 3..15 keep constants computed from the lane index; nothing
 // but the body itself is streamed from or to HBM.
 //
-// A wavefront pass covers one or more 64 KiB tiles.  The walk over objects is
-// done once per wavefront on the scalar unit: descriptors are fetched with
-// scalar loads (constant address space, one s_load_dwordx16 each) and the next
-// one is prefetched into SGPRs, so waiting for a descriptor never drains the
-// vector-memory queue that holds the body's stores or prefetched loads.
+// Both passes are launched as short-lived workgroups of 256 threads in address
+// order (fill: one 16-byte store per thread, a workgroup per 4 KiB chunk;
+// validate: four loads per thread, a wavefront per chunk).  The accesses in
+// flight then cover a few MiB that sweep the body once, which this memory
+// system sustains 10-17 % faster (writes) and ~3 % faster (reads) than
+// persistent wavefronts that each stream a tile of their own (measured with
+// tools/write_shapes.hip and with earlier persistent versions of these kernels).
+//
+// The walk over objects is done once per wavefront on the scalar unit: the
+// chunk table names the first object of the chunk, descriptors are fetched
+// with scalar loads (constant address space, one s_load_dwordx16 each), and a
+// wavefront walks forward only across the object boundaries inside its range.
 //
 // Stores are non-temporal: a fill that leaves its lines dirty in L2 / Infinity
 // Cache makes the validate pass that follows pay for their write-back (measured:
@@ -28,6 +35,7 @@ namespace oval {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) u32x4* sdesc_ptr;
+typedef const __attribute__((address_space(4))) uint32_t* sidx_ptr;
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
@@ -41,16 +49,17 @@ __device__ __forceinline__ uint32_t reg_byte(const u32x4& v, int i)
 }
 
 // ---------------------------------------------------------------------------
-// tile table: tile t -> first object whose end lies beyond unit 256 t
+// chunk table: chunk c (4 KiB = 16 units) -> first object whose end lies beyond
+// unit 16 c.  A 64 KiB tile starts at chunk 16 t.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void build_tile_table_kernel(const u32x4* __restrict__ descs,
-                                                               uint32_t n_obj,
-                                                               uint32_t* __restrict__ tile_first,
-                                                               uint32_t n_tiles)
+__global__ __launch_bounds__(256) void build_chunk_table_kernel(const u32x4* __restrict__ descs,
+                                                                uint32_t n_obj,
+                                                                uint32_t* __restrict__ chunk_first,
+                                                                uint32_t n_chunks)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    const uint32_t g = t * kUnitsPerTile;
+    if (t >= n_chunks) return;
+    const uint32_t g = t * kUnitsPerChunk;
     uint32_t lo = 0, hi = n_obj;                  // first o in [lo,hi] with end(o) > g
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -58,41 +67,7 @@ __global__ __launch_bounds__(256) void build_tile_table_kernel(const u32x4* __re
         const uint32_t end = ((s3.x >> 8) | (s3.y << 24)) + s3.z;
         if (end > g) hi = mid; else lo = mid + 1;
     }
-    tile_first[t] = lo;
-}
-
-// ---------------------------------------------------------------------------
-// which passes a wavefront takes
-// ---------------------------------------------------------------------------
-// variant 0: grid-stride (all wavefronts sweep the buffer together).
-// variant 1: workgroups that share an XCD (equal blockIdx % 8) take one
-//            contiguous eighth of the passes.
-__device__ __forceinline__ uint32_t first_pass(uint32_t begin, uint32_t end_in, int variant,
-                                               uint32_t& end, uint32_t& stride)
-{
-    const uint32_t wave_in_block = threadIdx.x >> 6;
-    const uint32_t wpb = kBlockThreads / 64;
-    uint32_t first;
-    if (variant == 1 && (gridDim.x & 7u) == 0) {
-        const uint32_t xcd = blockIdx.x & 7u;
-        const uint32_t blk = blockIdx.x >> 3;
-        const uint32_t per = (end_in - begin + 7u) >> 3;
-        uint32_t b = begin + xcd * per;
-        uint32_t e = b + per;
-        if (b > end_in) b = end_in;
-        if (e > end_in) e = end_in;
-        first = b + blk * wpb + wave_in_block;
-        end = e;
-        stride = (gridDim.x >> 3) * wpb;
-    } else {
-        first = begin + blockIdx.x * wpb + wave_in_block;
-        end = end_in;
-        stride = gridDim.x * wpb;
-    }
-    // wave-uniform by construction; tell the compiler so (scalar loop control)
-    end = __builtin_amdgcn_readfirstlane(end);
-    stride = __builtin_amdgcn_readfirstlane(stride);
-    return __builtin_amdgcn_readfirstlane(first);
+    chunk_first[t] = lo;
 }
 
 // ---------------------------------------------------------------------------
@@ -103,14 +78,13 @@ struct WObj {                    // the current object
     u32x4 d0, d1, d2;            // bytes [0,48) of the descriptor = header template
 };
 
-struct WRaw {                    // a descriptor fetched ahead of need, not yet decoded
+struct WRaw {                    // a fetched descriptor, not yet decoded
     uint32_t o;
     u32x4 d0, d1, d2, d3;
 };
 
-// n_obj >= 1.  The load is unconditional (index clamped to the last object) so
-// that nothing touches the destination registers before the values are needed:
-// the wait for it then sits at the next object switch, not here.
+// n_obj >= 1.  The load is unconditional (index clamped to the last object);
+// r.o == n_obj then says "no such object".
 __device__ __forceinline__ void w_fetch(sdesc_ptr descs, uint32_t n_obj, uint32_t o, WRaw& r)
 {
     const uint32_t oc = o < n_obj ? o : n_obj - 1u;
@@ -123,9 +97,6 @@ __device__ __forceinline__ void w_fetch(sdesc_ptr descs, uint32_t n_obj, uint32_
 
 __device__ __forceinline__ void w_activate(const WRaw& r, uint32_t n_obj, WObj& w)
 {
-    // Every fetched register counts as read here, so none of them is handed
-    // out as a temporary (and waited for) while the fetch is still in flight.
-    asm volatile("" ::"s"(r.d0), "s"(r.d1), "s"(r.d2), "s"(r.d3));
     w.o = r.o;
     w.d0 = r.d0; w.d1 = r.d1; w.d2 = r.d2;
     if (r.o < n_obj) {
@@ -137,21 +108,6 @@ __device__ __forceinline__ void w_activate(const WRaw& r, uint32_t n_obj, WObj& 
         w.start = kNone; w.end = kNone; w.lf = 0; w.ubias = 0; // no more objects
     }
 }
-
-// Make object `o` current and start fetching its successor.
-__device__ __forceinline__ void w_enter(sdesc_ptr descs, uint32_t n_obj, uint32_t o, WObj& w, WRaw& next)
-{
-    WRaw r;
-    w_fetch(descs, n_obj, o, r);
-    w_fetch(descs, n_obj, o + 1u, next);
-    w_activate(r, n_obj, w);
-}
-
-// Stepping to the successor is done in two halves by the kernels: w_activate
-// + rebuilding the lane template (which reads the fetched registers), then,
-// behind a scheduling barrier, w_fetch of the one after it.  Issued earlier,
-// the fetch would need registers of its own and be copied (and waited for)
-// on the spot.
 
 // This lane's expected 16 bytes; lane 2's .x gets + (g << 8) per unit, which
 // makes uint32(unitCount * 256) (pattern.go:96,102).
@@ -174,10 +130,14 @@ __device__ __forceinline__ uint32_t w_lane_force(const WObj& w, int j)
 // ---------------------------------------------------------------------------
 // fill: Generate / generateDataUnit (pattern.go:73-116) for a whole batch
 // ---------------------------------------------------------------------------
-template <int UNROLL, int PASS>   // PASS = tiles per wavefront pass
-__global__ __launch_bounds__(256) void fill_kernel(sdesc_ptr descs, const uint32_t* __restrict__ tile_first,
-                                                   uint32_t n_obj, u32x4* __restrict__ body,
-                                                   uint32_t tile_begin, uint32_t tile_end, int variant)
+// One 16-byte store per thread; workgroup b covers units [unit_begin + b *
+// THREADS/16, ...).  A wavefront (4 consecutive units) finds its object from
+// the chunk table and walks forward only across the object boundaries inside
+// its 1 KiB; units that belong to no object (gaps, the tail of the last tile)
+// are not written.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void fill_kernel(sdesc_ptr descs, sidx_ptr chunk_first, uint32_t n_obj,
+                                                       u32x4* __restrict__ body, uint32_t unit_begin)
 {
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
@@ -185,39 +145,23 @@ __global__ __launch_bounds__(256) void fill_kernel(sdesc_ptr descs, const uint32
     const uint32_t gmul = (j == 2) ? 256u : 0u;
     const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
                         filler_dword(4u * j + 3u)};
-    uint32_t p_end, p_stride;
-    for (uint32_t pass = first_pass(tile_begin / PASS, (tile_end + PASS - 1) / PASS, variant, p_end, p_stride);
-         pass < p_end; pass += p_stride) {
-        const uint32_t tile = pass * PASS;
-        const uint32_t g_tile = tile * kUnitsPerTile;
-        WObj w;
-        WRaw next;
-        w_enter(descs, n_obj, __builtin_amdgcn_readfirstlane(tile_first[tile]), w, next);
-        u32x4 tmpl = w_lane_template(w, j, cpat);
-        u32x4* const tile_ptr = body + (size_t)g_tile * 16u + (uint32_t)lane;
-#pragma unroll UNROLL
-        for (uint32_t k = 0; k < (kUnitsPerTile / 4u) * PASS; ++k) {
-            const uint32_t g4 = g_tile + 4u * k;
-            const uint32_t g = g4 + grp;
-            if (g4 >= w.start && g4 + 4u <= w.end) {            // all four units inside the object
-                u32x4 e = tmpl;
-                e.x += g * gmul;
-                __builtin_nontemporal_store(e, tile_ptr + (size_t)k * 64u);
-            } else {                                            // boundary, gap, or past the last object
-                for (;;) {
-                    if (g >= w.start && g < w.end) {
-                        u32x4 e = tmpl;
-                        e.x += g * gmul;
-                        __builtin_nontemporal_store(e, tile_ptr + (size_t)k * 64u);
-                    }
-                    if (w.end >= g4 + 4u) break;                 // kNone for "no more objects"
-                    w_activate(next, n_obj, w);
-                    tmpl = w_lane_template(w, j, cpat);
-                    __builtin_amdgcn_sched_barrier(0);
-                    w_fetch(descs, n_obj, w.o + 1u, next);
-                }
-            }
+    const uint32_t g4 = unit_begin + blockIdx.x * (THREADS / 16u) +
+                        __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 4u;
+    const uint32_t g = g4 + grp;
+    WRaw r;
+    WObj w;
+    w_fetch(descs, n_obj, chunk_first[g4 / kUnitsPerChunk], r);
+    w_activate(r, n_obj, w);
+    u32x4* const p = body + (size_t)g4 * 16u + (uint32_t)lane;
+    for (;;) {
+        if (g >= w.start && g < w.end) {
+            u32x4 e = w_lane_template(w, j, cpat);
+            e.x += g * gmul;
+            __builtin_nontemporal_store(e, p);
         }
+        if (w.end >= g4 + 4u) break;                             // kNone for "no more objects"
+        w_fetch(descs, n_obj, w.o + 1u, r);
+        w_activate(r, n_obj, w);
     }
 }
 
@@ -237,10 +181,20 @@ struct WTotals {
     uint32_t units, bucket, key, wc, off, wid, strict;
 };
 
+// Bad-unit tallies go to one of kTallyStripes copies of the counter vector (one
+// cache line each, picked by workgroup), not to the caller's counters: with
+// every wavefront of a badly corrupted batch adding to the same line, the
+// atomics serialise (measured: 70 ms instead of 1.3 ms for a cfg2 batch whose
+// every unit is bad).  fold_tallies_kernel adds the stripes up afterwards.
+__device__ __forceinline__ unsigned long long* tally_of(unsigned long long* stripes)
+{
+    return stripes + (size_t)(blockIdx.x & (kTallyStripes - 1u)) * kTallyStride;
+}
+
 // One lane publishes the wavefront's outcome for object w.o: a 64-bit
 // atomicMin keeps the lowest bad unit together with its field mask.
 __device__ __forceinline__ void w_flush(oval_obj_result* __restrict__ results,
-                                        unsigned long long* __restrict__ counters, const WObj& w, WRun& r,
+                                        unsigned long long* __restrict__ stripes, const WObj& w, WRun& r,
                                         int lane)
 {
     if (r.cnt != 0u || r.sfirst != kNone) {
@@ -251,11 +205,28 @@ __device__ __forceinline__ void w_flush(oval_obj_result* __restrict__ results,
                     ((unsigned long long)(r.first + w.ubias) << 32) | (unsigned long long)r.mask;
                 atomicMin(reinterpret_cast<unsigned long long*>(R), key);
                 const uint32_t old = atomicAdd(&R->bad_units, r.cnt);
-                if (old == 0u && counters) atomicAdd(&counters[OVAL_CNT_OBJECTS_BAD], 1ull);
+                if (old == 0u && stripes) atomicAdd(&tally_of(stripes)[OVAL_CNT_OBJECTS_BAD], 1ull);
             }
             atomicMin(&R->strict_first_bad_unit, r.sfirst + w.ubias);
         }
         r.first = kNone; r.mask = 0; r.cnt = 0; r.sfirst = kNone;
+    }
+}
+
+// Adds a wavefront's bad-unit tallies to its workgroup's stripe (nothing to do
+// for a clean wavefront: every reference-visible mismatch is also a strict one).
+__device__ __forceinline__ void w_totals_flush(unsigned long long* __restrict__ stripes, const WTotals& tot,
+                                               int lane)
+{
+    if (stripes && tot.strict != 0u && lane == 0) {
+        unsigned long long* counters = tally_of(stripes);
+        if (tot.units) atomicAdd(&counters[OVAL_CNT_UNITS_BAD], (unsigned long long)tot.units);
+        if (tot.bucket) atomicAdd(&counters[OVAL_CNT_BAD_BUCKET], (unsigned long long)tot.bucket);
+        if (tot.key) atomicAdd(&counters[OVAL_CNT_BAD_KEY], (unsigned long long)tot.key);
+        if (tot.wc) atomicAdd(&counters[OVAL_CNT_BAD_WRITECNT], (unsigned long long)tot.wc);
+        if (tot.off) atomicAdd(&counters[OVAL_CNT_BAD_OFFSET], (unsigned long long)tot.off);
+        if (tot.wid) atomicAdd(&counters[OVAL_CNT_BAD_WORKER], (unsigned long long)tot.wid);
+        atomicAdd(&counters[OVAL_CNT_STRICT_UNITS_BAD], (unsigned long long)tot.strict);
     }
 }
 
@@ -326,13 +297,14 @@ __device__ __forceinline__ uint32_t w_diff(const u32x4& v, uint32_t ex, const u3
     return (v.x ^ ex) | (v.y ^ tmpl.y) | (((v.z ^ tmpl.z) | (v.w ^ tmpl.w)) & zwmask);
 }
 
-template <int UNROLL, int PASS>
-__global__ __launch_bounds__(256) void validate_kernel(sdesc_ptr descs, const uint32_t* __restrict__ tile_first,
-                                                       uint32_t n_obj, uint32_t limit_units,
-                                                       const u32x4* __restrict__ body,
-                                                       uint32_t tile_begin, uint32_t tile_end,
-                                                       oval_obj_result* __restrict__ results,
-                                                       unsigned long long* __restrict__ counters, int variant)
+// Four loads per thread: a wavefront takes one whole 4 KiB chunk (wave-
+// contiguous), issues its loads, looks its object up while they are in flight,
+// then compares; only a wavefront that sees a mismatch runs the exact verdicts
+// (on the registers it already holds).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void validate_kernel(
+    sdesc_ptr descs, sidx_ptr chunk_first, uint32_t n_obj, uint32_t limit_units, const u32x4* __restrict__ body,
+    uint32_t chunk_begin, oval_obj_result* __restrict__ results, unsigned long long* __restrict__ stripes)
 {
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
@@ -341,94 +313,84 @@ __global__ __launch_bounds__(256) void validate_kernel(sdesc_ptr descs, const ui
     const uint32_t zwmask = (j == 2) ? 0u : 0xFFFFFFFFu;       // pattern.go:172 "Skip the unix time area."
     const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
                         filler_dword(4u * j + 3u)};
-    WTotals tot = {0, 0, 0, 0, 0, 0, 0};
-    uint32_t p_end, p_stride;
-    for (uint32_t pass = first_pass(tile_begin / PASS, (tile_end + PASS - 1) / PASS, variant, p_end, p_stride);
-         pass < p_end; pass += p_stride) {
-        const uint32_t tile = pass * PASS;
-        const uint32_t g_tile = tile * kUnitsPerTile;
-        WObj w;
-        WRaw next;
-        w_enter(descs, n_obj, __builtin_amdgcn_readfirstlane(tile_first[tile]), w, next);
-        u32x4 tmpl = w_lane_template(w, j, cpat);
-        uint32_t force = w_lane_force(w, j);
-        WRun run = {kNone, 0, 0, kNone};
-        const u32x4* const tile_ptr = body + (size_t)g_tile * 16u + (uint32_t)lane;
-
-        for (uint32_t kb = 0; kb < (kUnitsPerTile / 4u) * PASS; kb += UNROLL) {
-            bool careful = (run.cnt != 0u) || (run.sfirst != kNone);
-            const uint32_t o_batch = w.o;
-            if (!careful) {
-                // pass 1: stream the batch; no side effects until it is known to be clean
-                u32x4 v[UNROLL];
+    const uint32_t chunk = chunk_begin + blockIdx.x * (THREADS / 64u) +
+                           __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g0 = chunk * kUnitsPerChunk;
+    const u32x4* const p = body + (size_t)g0 * 16u + (uint32_t)lane;
+    u32x4 v[4];
 #pragma unroll
-                for (int i = 0; i < UNROLL; ++i) {
-                    v[i] = (u32x4){0u, 0u, 0u, 0u};
-                    if (g_tile + 4u * (kb + i) + grp < limit_units)
-                        v[i] = __builtin_nontemporal_load(tile_ptr + (size_t)(kb + i) * 64u);
-                }
-                uint32_t anybad = 0;
+    for (int i = 0; i < 4; ++i) {
+        v[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (g0 + 4u * i + grp < limit_units) v[i] = __builtin_nontemporal_load(p + (size_t)i * 64u);
+    }
+    const uint32_t o0 = chunk_first[chunk];
+    WRaw r;
+    WObj w;
+    w_fetch(descs, n_obj, o0, r);
+    w_activate(r, n_obj, w);
+    u32x4 tmpl = w_lane_template(w, j, cpat);
+    uint32_t force = w_lane_force(w, j);
+    uint32_t anybad = 0;
 #pragma unroll
-                for (int i = 0; i < UNROLL; ++i) {
-                    const uint32_t g4 = g_tile + 4u * (kb + i);
-                    const uint32_t g = g4 + grp;
-                    if (g4 >= w.start && g4 + 4u <= w.end) {
-                        anybad |= w_diff(v[i], tmpl.x + g * gmul, tmpl, zwmask) | force;
-                    } else {
-                        for (;;) {
-                            if (g >= w.start && g < w.end)
-                                anybad |= w_diff(v[i], tmpl.x + g * gmul, tmpl, zwmask) | force;
-                            if (w.end >= g4 + 4u) break;
-                            w_activate(next, n_obj, w);
-                            tmpl = w_lane_template(w, j, cpat);
-                            force = w_lane_force(w, j);
-                            __builtin_amdgcn_sched_barrier(0);
-                            w_fetch(descs, n_obj, w.o + 1u, next);
-                        }
-                    }
-                }
-                if (__any(anybad != 0u)) {
-                    careful = true;                             // rewind to the batch's first object
-                    w_enter(descs, n_obj, o_batch, w, next);
-                    tmpl = w_lane_template(w, j, cpat);
-                    force = w_lane_force(w, j);
-                }
-            }
-            if (careful) {
-                // pass 2: the same units one instruction at a time, with the exact verdicts
-#pragma unroll 1
-                for (int i = 0; i < UNROLL; ++i) {
-                    const uint32_t g4 = g_tile + 4u * (kb + i);
-                    const uint32_t g = g4 + grp;
-                    u32x4 v = {0u, 0u, 0u, 0u};
-                    if (g < limit_units) v = __builtin_nontemporal_load(tile_ptr + (size_t)(kb + i) * 64u);
-                    for (;;) {
-                        const uint32_t ex = tmpl.x + g * gmul;
-                        const bool bad = (g >= w.start && g < w.end) &&
-                                         ((w_diff(v, ex, tmpl, zwmask) | force) != 0u);
-                        if (__any(bad)) w_handle_bad(v, ex, tmpl, w.lf, force, bad, j, g4, run, tot);
-                        if (w.end >= g4 + 4u) break;
-                        w_flush(results, counters, w, run, lane);
-                        w_activate(next, n_obj, w);
-                        tmpl = w_lane_template(w, j, cpat);
-                        force = w_lane_force(w, j);
-                        __builtin_amdgcn_sched_barrier(0);
-                        w_fetch(descs, n_obj, w.o + 1u, next);
-                    }
-                }
-            }
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t g4 = g0 + 4u * i;
+        const uint32_t g = g4 + grp;
+        for (;;) {
+            if (g >= w.start && g < w.end) anybad |= w_diff(v[i], tmpl.x + g * gmul, tmpl, zwmask) | force;
+            if (w.end >= g4 + 4u) break;
+            w_fetch(descs, n_obj, w.o + 1u, r);
+            w_activate(r, n_obj, w);
+            tmpl = w_lane_template(w, j, cpat);
+            force = w_lane_force(w, j);
         }
-        if (w.o < n_obj) w_flush(results, counters, w, run, lane);
     }
-    if (counters && tot.strict != 0u && lane == 0) {
-        if (tot.units) atomicAdd(&counters[OVAL_CNT_UNITS_BAD], (unsigned long long)tot.units);
-        if (tot.bucket) atomicAdd(&counters[OVAL_CNT_BAD_BUCKET], (unsigned long long)tot.bucket);
-        if (tot.key) atomicAdd(&counters[OVAL_CNT_BAD_KEY], (unsigned long long)tot.key);
-        if (tot.wc) atomicAdd(&counters[OVAL_CNT_BAD_WRITECNT], (unsigned long long)tot.wc);
-        if (tot.off) atomicAdd(&counters[OVAL_CNT_BAD_OFFSET], (unsigned long long)tot.off);
-        if (tot.wid) atomicAdd(&counters[OVAL_CNT_BAD_WORKER], (unsigned long long)tot.wid);
-        atomicAdd(&counters[OVAL_CNT_STRICT_UNITS_BAD], (unsigned long long)tot.strict);
+    if (!__any(anybad != 0u)) return;
+
+    w_fetch(descs, n_obj, o0, r);
+    w_activate(r, n_obj, w);
+    tmpl = w_lane_template(w, j, cpat);
+    force = w_lane_force(w, j);
+    WRun run = {kNone, 0, 0, kNone};
+    WTotals tot = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t g4 = g0 + 4u * i;
+        const uint32_t g = g4 + grp;
+        const u32x4 vi = i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3];
+        for (;;) {
+            const uint32_t ex = tmpl.x + g * gmul;
+            const bool bad = (g >= w.start && g < w.end) && ((w_diff(vi, ex, tmpl, zwmask) | force) != 0u);
+            if (__any(bad)) w_handle_bad(vi, ex, tmpl, w.lf, force, bad, j, g4, run, tot);
+            if (w.end >= g4 + 4u) break;
+            w_flush(results, stripes, w, run, lane);
+            w_fetch(descs, n_obj, w.o + 1u, r);
+            w_activate(r, n_obj, w);
+            tmpl = w_lane_template(w, j, cpat);
+            force = w_lane_force(w, j);
+        }
     }
+    if (w.o < n_obj) w_flush(results, stripes, w, run, lane);
+    w_totals_flush(stripes, tot, lane);
+}
+
+// counters += sum of the stripes; the stripes return to zero for the next pass.
+__global__ __launch_bounds__(256) void fold_tallies_kernel(unsigned long long* __restrict__ stripes,
+                                                           unsigned long long* __restrict__ counters)
+{
+    static_assert(kTallyStripes == 256, "one thread per stripe");
+    __shared__ unsigned long long sum[OVAL_NUM_COUNTERS];
+    if (threadIdx.x < OVAL_NUM_COUNTERS) sum[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long* mine = stripes + (size_t)threadIdx.x * kTallyStride;
+    for (int c = 0; c < OVAL_NUM_COUNTERS; ++c) {
+        const unsigned long long x = mine[c];
+        if (x) {
+            atomicAdd(&sum[c], x);
+            mine[c] = 0ull;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < OVAL_NUM_COUNTERS && sum[threadIdx.x]) atomicAdd(&counters[threadIdx.x], sum[threadIdx.x]);
 }
 
 // results[i] = {none, none, 0, none}; counters += objects/units checked
@@ -448,43 +410,34 @@ __global__ __launch_bounds__(256) void init_results_kernel(u32x4* __restrict__ r
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-hipError_t launch_build_tile_table(hipStream_t s, const void* descs, uint32_t n_obj,
-                                   uint32_t* tile_first, uint32_t n_tiles)
+hipError_t launch_build_chunk_table(hipStream_t s, const void* descs, uint32_t n_obj,
+                                    uint32_t* chunk_first, uint32_t n_tiles)
 {
     if (n_tiles == 0) return hipSuccess;
-    const uint32_t blocks = (n_tiles + 255u) / 256u;
-    build_tile_table_kernel<<<blocks, 256, 0, s>>>(static_cast<const u32x4*>(descs), n_obj, tile_first, n_tiles);
+    const uint32_t n_chunks = n_tiles * kChunksPerTile;
+    const uint32_t blocks = (n_chunks + 255u) / 256u;
+    build_chunk_table_kernel<<<blocks, 256, 0, s>>>(static_cast<const u32x4*>(descs), n_obj, chunk_first, n_chunks);
     return hipGetLastError();
 }
 
-static int clamp_grid(int want, uint32_t n_passes)
-{
-    const uint32_t wpb = kBlockThreads / 64;
-    const uint32_t need = (n_passes + wpb - 1) / wpb;
-    if (need < (uint32_t)want) {
-        // keep the grid a multiple of 8 so the XCD mapping stays balanced
-        const uint32_t g = (need + 7u) & ~7u;
-        return (int)(g ? g : 8u);
-    }
-    return want;
-}
-
-// variant bits 4-5 select the kernel shape (benchmarks): 0 = shipped.
+// A launch covers whole tiles; units of the last tile beyond the span map to
+// "no more objects" in the chunk table and are neither stored nor loaded.
 hipError_t launch_fill(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv, void* body,
                        uint32_t tile_begin, uint32_t tile_end)
 {
-    if (tile_end <= tile_begin || lv.n_obj == 0) return hipSuccess;
     if (tile_end > lv.n_tiles) tile_end = lv.n_tiles;
-    const int grid = clamp_grid(cfg.grid_blocks, tile_end - tile_begin);
-    const int variant = cfg.variant & 1;
+    if (tile_end <= tile_begin || lv.n_obj == 0) return hipSuccess;
     sdesc_ptr sd = (sdesc_ptr)lv.descs;
+    sidx_ptr cf = (sidx_ptr)lv.chunk_first;
     u32x4* b = static_cast<u32x4*>(body);
-#define OVAL_LAUNCH_FILL(U, P) fill_kernel<U, P><<<grid, kBlockThreads, 0, s>>>(sd, lv.tile_first, lv.n_obj, b, tile_begin, tile_end, variant)
-    switch ((cfg.variant >> 4) & 3) {
-    case 1: OVAL_LAUNCH_FILL(8, 1); break;
-    case 2: OVAL_LAUNCH_FILL(4, 2); break;
-    case 3: OVAL_LAUNCH_FILL(4, 4); break;
-    default: OVAL_LAUNCH_FILL(4, 1); break;
+    const uint32_t unit_begin = tile_begin * kUnitsPerTile;
+    const uint32_t n_units = (tile_end - tile_begin) * kUnitsPerTile;
+#define OVAL_LAUNCH_FILL(T) fill_kernel<T><<<n_units / (T / 16), T, 0, s>>>(sd, cf, lv.n_obj, b, unit_begin)
+    switch (cfg.fill_threads) {
+    case 128: OVAL_LAUNCH_FILL(128); break;
+    case 512: OVAL_LAUNCH_FILL(512); break;
+    case 1024: OVAL_LAUNCH_FILL(1024); break;
+    default: OVAL_LAUNCH_FILL(256); break;
     }
 #undef OVAL_LAUNCH_FILL
     return hipGetLastError();
@@ -501,24 +454,31 @@ hipError_t launch_init_results(hipStream_t s, const LayoutView& lv, oval_obj_res
     return hipGetLastError();
 }
 
+// `stripes`: kTallyStripes * kTallyStride zeroed u64 owned by the stream's context
+// (left zeroed again); unused when the caller wants no counters.
 hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv,
                            const void* body, uint32_t tile_begin, uint32_t tile_end,
-                           oval_obj_result* results, unsigned long long* counters)
+                           oval_obj_result* results, unsigned long long* counters, unsigned long long* stripes)
 {
-    if (tile_end <= tile_begin || lv.n_obj == 0) return hipSuccess;
     if (tile_end > lv.n_tiles) tile_end = lv.n_tiles;
-    const int grid = clamp_grid(cfg.grid_blocks, tile_end - tile_begin);
-    const int variant = cfg.variant & 1;
+    if (tile_end <= tile_begin || lv.n_obj == 0) return hipSuccess;
     sdesc_ptr sd = (sdesc_ptr)lv.descs;
+    sidx_ptr cf = (sidx_ptr)lv.chunk_first;
     const u32x4* b = static_cast<const u32x4*>(body);
-#define OVAL_LAUNCH_VAL(U, P) validate_kernel<U, P><<<grid, kBlockThreads, 0, s>>>(sd, lv.tile_first, lv.n_obj, lv.span_units, b, tile_begin, tile_end, results, counters, variant)
-    switch ((cfg.variant >> 4) & 3) {
-    case 1: OVAL_LAUNCH_VAL(8, 1); break;
-    case 2: OVAL_LAUNCH_VAL(4, 2); break;
-    case 3: OVAL_LAUNCH_VAL(2, 1); break;
-    default: OVAL_LAUNCH_VAL(4, 1); break;
+    unsigned long long* tallies = counters ? stripes : nullptr;
+    const uint32_t chunk_begin = tile_begin * kChunksPerTile;
+    const uint32_t n_chunks = (tile_end - tile_begin) * kChunksPerTile;
+#define OVAL_LAUNCH_VAL(T) validate_kernel<T><<<n_chunks / (T / 64), T, 0, s>>>(sd, cf, lv.n_obj, lv.span_units, b, chunk_begin, results, tallies)
+    switch (cfg.validate_threads) {
+    case 128: OVAL_LAUNCH_VAL(128); break;
+    case 512: OVAL_LAUNCH_VAL(512); break;
+    case 1024: OVAL_LAUNCH_VAL(1024); break;
+    default: OVAL_LAUNCH_VAL(256); break;
     }
 #undef OVAL_LAUNCH_VAL
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !counters) return e;
+    fold_tallies_kernel<<<1, 256, 0, s>>>(stripes, counters);
     return hipGetLastError();
 }
 

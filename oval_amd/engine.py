@@ -51,8 +51,9 @@ class Context:
     def handle(self):
         return self._h
 
-    def set_tuning(self, blocks_per_cu: int = 0, variant: int = 0) -> None:
-        check(_lib.lib().oval_ctx_set_tuning(self._h, blocks_per_cu, variant))
+    def set_tuning(self, fill_threads: int = 0, validate_threads: int = 0) -> None:
+        """Workgroup sizes of the two kernels (128/256/512/1024; 0 = default)."""
+        check(_lib.lib().oval_ctx_set_tuning(self._h, fill_threads, validate_threads))
 
     def sync(self) -> None:
         check(_lib.lib().oval_ctx_sync(self._h))
