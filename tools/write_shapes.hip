@@ -60,6 +60,35 @@ __global__ __launch_bounds__(THREADS) void once_wave_kernel(u32x4* __restrict__ 
     }
 }
 
+// once_kernel <256 thr, 4 KiB> with (a) a dependent scalar load chain in front of
+// the store, as the pattern kernels have (table -> 64-byte entry -> store), and
+// (b) dynamic LDS to bound the workgroups resident per CU.
+typedef const __attribute__((address_space(4))) u32x4* sc_u32x4;
+typedef const __attribute__((address_space(4))) uint32_t* sc_u32;
+// CHAIN 1: index per 64 KiB -> entry (mostly cache hits).  CHAIN 2: index per 4 KiB chunk -> an entry
+// every ~2.3 chunks (what a batch of 4-16 KiB objects looks like: both loads often miss the XCD's L2).
+// CHAIN 3: no index, one 64-byte entry per chunk read directly (one load, always a miss).
+template <int CHAIN>
+__global__ __launch_bounds__(256) void once_chain_kernel(u32x4* __restrict__ buf, sc_u32 first, sc_u32x4 table)
+{
+    extern __shared__ uint32_t dyn_lds[];
+    u32x4 v = {(uint32_t)threadIdx.x, 1u, 2u, 3u};
+    if (CHAIN == 1) {
+        const uint32_t e = first[blockIdx.x >> 4];
+        const u32x4 d = table[4u * e];
+        v.y += d.x;
+    } else if (CHAIN == 2) {
+        const uint32_t e = first[blockIdx.x];
+        const u32x4 d = table[4u * e];
+        v.y += d.x;
+    } else if (CHAIN == 3) {
+        const u32x4 d = table[4u * blockIdx.x];
+        v.y += d.x;
+    }
+    if (buf == nullptr) dyn_lds[threadIdx.x] = v.x;              // keeps the LDS allocation alive; never taken
+    __builtin_nontemporal_store(v, buf + (size_t)blockIdx.x * 256 + threadIdx.x);
+}
+
 // Read counterpart of once_kernel: PER loads per thread, all issued before use.
 template <int THREADS, int KIB, bool NTL>
 __global__ __launch_bounds__(THREADS) void once_read_kernel(const u32x4* __restrict__ buf, uint32_t* __restrict__ sink)
@@ -193,6 +222,28 @@ int main(int argc, char** argv)
     ONCEW(256, 256, false, "plain") ONCEW(256, 256, true, "nt")
     ONCEW(1024, 256, true, "nt") ONCEW(1024, 1024, true, "nt")
 
+    {
+        const uint32_t n_chunks = kib / 4;
+        std::vector<uint32_t> first(n_chunks);
+        for (uint32_t c = 0; c < n_chunks; ++c) first[c] = (uint32_t)(((uint64_t)c * 10) / 23);
+        const size_t n_entries = n_chunks;
+        uint32_t* d_first;
+        u32x4* table;
+        CHECK(hipMalloc(&d_first, n_chunks * 4));
+        CHECK(hipMalloc(&table, n_entries * 64));
+        CHECK(hipMemcpy(d_first, first.data(), n_chunks * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemset(table, 0, n_entries * 64));
+        for (int lds_kib : {0, 40}) {
+            char name[128];
+#define OC(C, LABEL)                                                                             \
+            snprintf(name, sizeof name, "once 256 thr x 4 KiB nt, %-28s %2d KiB LDS/wg", LABEL, lds_kib); \
+            time_it(name, bytes, [&] { once_chain_kernel<C><<<kib / 4, 256, lds_kib * 1024>>>(buf, (sc_u32)d_first, (sc_u32x4)table); });
+            OC(0, "no chain") OC(1, "2 loads, mostly hits") OC(2, "2 loads, per-chunk index") OC(3, "1 load, 64 B per chunk")
+#undef OC
+        }
+        CHECK(hipFree(d_first));
+        CHECK(hipFree(table));
+    }
     {
         // tile -> entry table like the library's: ascending, ~5.4 entries per tile, 64-byte entries
         std::vector<uint32_t> first(n_tiles);
