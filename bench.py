@@ -31,7 +31,7 @@ WORKLOADS = {
     # name: (objects per GPU, workers, min size, max size, description)
     "cfg2": (1_000_000, 64, 4096, 16384, "1M objects 4k-16k (DecideSize), fill+validate batch"),
     "cfg3": (64, 64, 256 << 20, 256 << 20, "64 objects x 256 MiB, fill+validate"),
-    "cfg5": (1_250_000, 50, 4096, 1 << 20, "resident batches of 4k-1M objects"),
+    "cfg5": (1_250_000, 50, 4096, 1 << 20, "1.25M objects 4k-1M per GPU (10M over 8), resident sub-batches"),
 }
 
 
@@ -104,14 +104,18 @@ def main():
     ap.add_argument("--validate-threads", type=int, default=0, help="workgroup size of the validate kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to "
+                    "rehearse more ranks than GPUs: ranks then share devices round-robin)")
     ap.add_argument("--sizes", default="", help="override object sizes, e.g. 65536-65536 (bytes, multiples of 256)")
+    ap.add_argument("--batch-gib", type=float, default=64.0,
+                    help="largest body buffer; a bigger workload runs as consecutive sub-batches through it")
     args = ap.parse_args()
 
     import torch
 
     from oval_amd import engine
-    from oval_amd.batch import span_bytes
-    from oval_amd.dist import all_reduce_counters
+    from oval_amd.batch import span_bytes, split_batches
+    from oval_amd.dist import all_reduce, all_reduce_counters
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,13 +124,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the pattern engine has no CPU path")
+    if args.backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     stream = torch.cuda.Stream(local)
     torch.cuda.set_stream(stream)
@@ -136,43 +145,49 @@ def main():
     size_override = tuple(int(x) for x in args.sizes.split("-")) if args.sizes else None
     descs = build_batch(args.workload, rank, args.objects, args.seed, size_override)
     n_obj, units = len(descs), int(descs["n_units"].sum())
-    nbytes = span_bytes(descs)
-    layout = engine.Layout(ctx, descs)
-    body = torch.empty(nbytes, dtype=torch.uint8, device=f"cuda:{local}")
-    results = torch.empty((n_obj, 4), dtype=torch.int32, device=body.device)
+    # One resident layout per sub-batch (descriptors + chunk table stay on the
+    # device), one body buffer reused by all of them.
+    parts = split_batches(descs, int(args.batch_gib * (1 << 30)))
+    nbytes = sum(span_bytes(p) for p in parts)
+    layouts = [engine.Layout(ctx, p) for p in parts]
+    body = torch.empty(max(span_bytes(p) for p in parts), dtype=torch.uint8, device=f"cuda:{local}")
+    results = [torch.empty((len(p), 4), dtype=torch.int32, device=body.device) for p in parts]
     counters = torch.zeros(engine.NUM_COUNTERS, dtype=torch.int64, device=body.device)
 
-    def step(tf=None, tv=None):
+    def step(timers=None):
         counters.zero_()
-        if tf: tf.start()
-        layout.fill(body)
-        if tf: tf.stop()
-        if tv: tv.start()
-        layout.validate(body, results, counters)
-        if tv: tv.stop()
+        for k, layout in enumerate(layouts):
+            tf, tv = timers[k] if timers else (None, None)
+            if tf: tf.start()
+            layout.fill(body)
+            if tf: tf.stop()
+            if tv: tv.start()
+            layout.validate(body, results[k], counters)
+            if tv: tv.stop()
         all_reduce_counters(counters)          # the one collective of a batch
 
     for _ in range(args.warmup):
         step()
-    timers = [(engine.Timer(ctx), engine.Timer(ctx)) for _ in range(args.steps)]
+    timers = [[(engine.Timer(ctx), engine.Timer(ctx)) for _ in layouts] for _ in range(args.steps)]
     torch.cuda.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for tf, tv in timers:
-        step(tf, tv)
+    for per_step in timers:
+        step(per_step)
     torch.cuda.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
 
-    fill_ms = float(np.mean([tf.elapsed_ms() for tf, _ in timers]))
-    val_ms = float(np.mean([tv.elapsed_ms() for _, tv in timers]))
+    # per step: the sum over sub-batches (one launch each); then the mean over steps
+    fill_ms = float(np.mean([sum(tf.elapsed_ms() for tf, _ in per_step) for per_step in timers]))
+    val_ms = float(np.mean([sum(tv.elapsed_ms() for _, tv in per_step) for per_step in timers]))
     tot = counters.cpu().numpy()
     stats = torch.tensor([wall, float(units)], dtype=torch.float64, device=body.device)
     if dist:
-        mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        mx = all_reduce(stats.clone(), dist.ReduceOp.MAX)
+        sm = all_reduce(stats.clone(), dist.ReduceOp.SUM)
         wall, units_all = float(mx[0]), float(sm[1])
     else:
         units_all = float(units)
@@ -193,7 +208,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+                if not (args.objects or args.sizes):             # measured on the default shape only
+                    traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
             except Exception:
                 traffic = None
         out = {
@@ -202,12 +218,13 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][4]}", "objects_per_gpu": n_obj,
-                       "units_per_gpu": units, "bytes_per_gpu": nbytes, "sharding": "worker key range (process ID = rank)",
+                       "units_per_gpu": units, "bytes_per_gpu": nbytes, "sub_batches": len(parts), "sharding": "worker key range (process ID = rank)",
                        "fill_threads": args.fill_threads or 256, "validate_threads": args.validate_threads or 256},
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": 256 * units, "avg_launch_ms": round(dom_ms, 4)},
+                         "algorithmic_bytes_per_launch": 256 * units // len(parts),
+                         "avg_launch_ms": round(dom_ms / len(parts), 4)},
             "kernels": {"fill_ms": round(fill_ms, 4), "fill_GBps": round(fill_gbs, 1),
                         "validate_ms": round(val_ms, 4), "validate_GBps": round(val_gbs, 1)},
         }

@@ -92,6 +92,30 @@ def build_descs(bucket: str | bytes, keys: np.ndarray, write_counts, worker_ids,
     return d
 
 
+def split_batches(descs: np.ndarray, max_bytes: int) -> list:
+    """Cuts a descriptor table (bodies back to back, ascending offsets) into
+    consecutive sub-batches whose bodies span at most `max_bytes` each, with
+    offsets rebased to 0: the pieces a body buffer of that size is reused for.
+    An object larger than max_bytes gets a sub-batch of its own."""
+    if len(descs) == 0:
+        return []
+    if max_bytes <= 0:
+        raise ValueError("max_bytes must be positive")
+    starts = descs["body_offset"].astype(np.uint64)
+    ends = starts + descs["n_units"].astype(np.uint64) * np.uint64(UNIT)
+    out, i, n = [], 0, len(descs)
+    while i < n:
+        base = starts[i]
+        # last object whose end still fits; ends[] ascends because the table does
+        j = int(np.searchsorted(ends, base + np.uint64(max_bytes), side="right"))
+        j = max(j, i + 1)
+        part = descs[i:j].copy()
+        part["body_offset"] -= base
+        out.append(part)
+        i = j
+    return out
+
+
 def span_bytes(descs: np.ndarray) -> int:
     if len(descs) == 0:
         return 0

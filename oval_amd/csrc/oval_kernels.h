@@ -15,6 +15,7 @@ namespace oval {
 constexpr uint32_t kUnitsPerChunk = 16;                    // 4 KiB
 constexpr uint32_t kChunksPerTile = 16;
 constexpr uint32_t kUnitsPerTile  = kUnitsPerChunk * kChunksPerTile;   // 64 KiB
+constexpr uint32_t kMaxTilesPerLaunch = 1u << 19;          // 32 GiB of body per kernel launch
 
 // Bad-unit tallies are spread over this many copies of the counter vector, one
 // 128-byte line each, and folded into the caller's counters after the pass.

@@ -71,6 +71,42 @@ __global__ __launch_bounds__(256) void build_chunk_table_kernel(const u32x4* __r
 }
 
 // ---------------------------------------------------------------------------
+// Reads the part of the chunk table and of the descriptor table that the
+// chunks [chunk_begin, chunk_end) refer to, so that it sits in the memory-side
+// cache when the pass over those chunks starts.  Every wavefront of a pass
+// starts with two dependent lookups (chunk table, descriptor); with 8 MiB of
+// body in flight per lookup latency, two cold HBM round trips under a saturated
+// write stream hold the fill at 3.3-4.8 TB/s where warm tables give 6.7-7.2
+// (the pre-pass itself costs under 1 %).  The validate kernel has its body loads
+// in flight while it looks up and does not need this (measured: no difference).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warm_tables_kernel(const u32x4* __restrict__ descs,
+                                                          const uint32_t* __restrict__ chunk_first,
+                                                          uint32_t n_obj, uint32_t chunk_begin, uint32_t chunk_end)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    // chunk_begin and chunk_end are multiples of kChunksPerTile, so the range is whole 64-byte lines
+    const u32x4* cf = reinterpret_cast<const u32x4*>(chunk_first + chunk_begin);
+    for (uint32_t i = tid; i < (chunk_end - chunk_begin) / 4u; i += stride) {
+        const u32x4 v = cf[i];
+        acc |= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    const uint32_t o_lo = chunk_first[chunk_begin];
+    uint32_t o_hi = chunk_first[chunk_end - 1u] + kUnitsPerChunk + 1u;   // a chunk holds at most 16 objects
+    if (o_hi > n_obj) o_hi = n_obj;
+    if (o_lo < o_hi) {
+        const u32x4* d = descs + (size_t)o_lo * 4u;
+        for (uint32_t i = tid; i < (o_hi - o_lo) * 4u; i += stride) {
+            const u32x4 v = d[i];
+            acc |= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    asm volatile("" ::"v"(acc));                                // the loads are the point
+}
+
+// ---------------------------------------------------------------------------
 // wave-uniform object walk
 // ---------------------------------------------------------------------------
 struct WObj {                    // the current object
@@ -430,17 +466,25 @@ hipError_t launch_fill(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv
     sdesc_ptr sd = (sdesc_ptr)lv.descs;
     sidx_ptr cf = (sidx_ptr)lv.chunk_first;
     u32x4* b = static_cast<u32x4*>(body);
-    const uint32_t unit_begin = tile_begin * kUnitsPerTile;
-    const uint32_t n_units = (tile_end - tile_begin) * kUnitsPerTile;
+    // One launch holds at most 2^31 threads (HIP refuses 2^32): 32 GiB of body for the fill.
+    for (uint32_t t0 = tile_begin; t0 < tile_end; t0 += kMaxTilesPerLaunch) {
+        const uint32_t t1 = tile_end - t0 > kMaxTilesPerLaunch ? t0 + kMaxTilesPerLaunch : tile_end;
+        const uint32_t unit_begin = t0 * kUnitsPerTile;
+        const uint32_t n_units = (t1 - t0) * kUnitsPerTile;
+        warm_tables_kernel<<<1024, 256, 0, s>>>(static_cast<const u32x4*>(lv.descs), lv.chunk_first, lv.n_obj,
+                                                t0 * kChunksPerTile, t1 * kChunksPerTile);
 #define OVAL_LAUNCH_FILL(T) fill_kernel<T><<<n_units / (T / 16), T, 0, s>>>(sd, cf, lv.n_obj, b, unit_begin)
-    switch (cfg.fill_threads) {
-    case 128: OVAL_LAUNCH_FILL(128); break;
-    case 512: OVAL_LAUNCH_FILL(512); break;
-    case 1024: OVAL_LAUNCH_FILL(1024); break;
-    default: OVAL_LAUNCH_FILL(256); break;
-    }
+        switch (cfg.fill_threads) {
+        case 128: OVAL_LAUNCH_FILL(128); break;
+        case 512: OVAL_LAUNCH_FILL(512); break;
+        case 1024: OVAL_LAUNCH_FILL(1024); break;
+        default: OVAL_LAUNCH_FILL(256); break;
+        }
 #undef OVAL_LAUNCH_FILL
-    return hipGetLastError();
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_init_results(hipStream_t s, const LayoutView& lv, oval_obj_result* results,
@@ -466,18 +510,22 @@ hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView
     sidx_ptr cf = (sidx_ptr)lv.chunk_first;
     const u32x4* b = static_cast<const u32x4*>(body);
     unsigned long long* tallies = counters ? stripes : nullptr;
-    const uint32_t chunk_begin = tile_begin * kChunksPerTile;
-    const uint32_t n_chunks = (tile_end - tile_begin) * kChunksPerTile;
+    for (uint32_t t0 = tile_begin; t0 < tile_end; t0 += kMaxTilesPerLaunch) {
+        const uint32_t t1 = tile_end - t0 > kMaxTilesPerLaunch ? t0 + kMaxTilesPerLaunch : tile_end;
+        const uint32_t chunk_begin = t0 * kChunksPerTile;
+        const uint32_t n_chunks = (t1 - t0) * kChunksPerTile;
 #define OVAL_LAUNCH_VAL(T) validate_kernel<T><<<n_chunks / (T / 64), T, 0, s>>>(sd, cf, lv.n_obj, lv.span_units, b, chunk_begin, results, tallies)
-    switch (cfg.validate_threads) {
-    case 128: OVAL_LAUNCH_VAL(128); break;
-    case 512: OVAL_LAUNCH_VAL(512); break;
-    case 1024: OVAL_LAUNCH_VAL(1024); break;
-    default: OVAL_LAUNCH_VAL(256); break;
-    }
+        switch (cfg.validate_threads) {
+        case 128: OVAL_LAUNCH_VAL(128); break;
+        case 512: OVAL_LAUNCH_VAL(512); break;
+        case 1024: OVAL_LAUNCH_VAL(1024); break;
+        default: OVAL_LAUNCH_VAL(256); break;
+        }
 #undef OVAL_LAUNCH_VAL
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || !counters) return e;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (!counters) return hipSuccess;
     fold_tallies_kernel<<<1, 256, 0, s>>>(stripes, counters);
     return hipGetLastError();
 }

@@ -31,11 +31,25 @@ def shard_batch(space: WorkerSpace, world_size: int, rank: int, bucket: str, min
     return synthetic_batch(space, workers, bucket, min_size, max_size, seed, unix_micro)
 
 
+def all_reduce(t, op=None):
+    """dist.all_reduce in place; a device tensor under the gloo backend (CPU
+    rehearsal of the multi-GPU path on a box with fewer GPUs than ranks) goes
+    through host memory."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return t
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=op)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def all_reduce_counters(counters):
     """Sums the (12,) int64 counter vector over all ranks, in place: the single
     collective of a batch."""
-    import torch.distributed as dist
-
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
-    return counters
+    return all_reduce(counters)

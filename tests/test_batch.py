@@ -96,3 +96,25 @@ def test_corruption_plan_agrees_with_oracle(oracle):
         assert res["first_bad_unit"][o] == plan.stale_unit[plan.stale_obj == o].min()
         assert res["first_bad_fields"][o] == 4
     assert cnt[1] == len(bad) and cnt[3] == res["bad_units"].sum()
+
+
+def test_split_batches_rebases_and_covers():
+    from oval_amd.batch import split_batches, span_bytes
+    sizes = np.array([4096, 8192, 256, 65536, 4096, 1 << 20, 512, 512], dtype=np.int64)
+    d = build_descs("b", make_keys(np.arange(len(sizes))), 1, 2, 3, sizes)
+    parts = split_batches(d, 70000)
+    assert sum(len(p) for p in parts) == len(d)
+    assert [int(p["body_offset"][0]) for p in parts] == [0] * len(parts)
+    for p in parts:
+        assert span_bytes(p) <= 70000 or len(p) == 1            # the 1 MiB object stands alone
+    cat = np.concatenate(parts)
+    for f in ("bucket", "key", "write_count", "worker_id", "n_units", "first_unit"):
+        assert (cat[f] == d[f]).all()
+    # offsets inside a part keep the original spacing
+    k = 0
+    for p in parts:
+        assert (p["body_offset"] == d["body_offset"][k:k + len(p)] - d["body_offset"][k]).all()
+        k += len(p)
+    assert split_batches(d[:0], 100) == []
+    with pytest.raises(ValueError):
+        split_batches(d, 0)
