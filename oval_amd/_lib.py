@@ -109,6 +109,40 @@ SIGNATURES = {
     "oval_pattern_dump": (_sz, [_cp, _sz, _cp, _sz]),
     "oval_pattern_hex_dump": (_sz, [_vp, _sz, _cp, _sz]),
     "oval_object_generate_key": (_sz, [_i64, _cp, _sz]),
+    # oval_context.h
+    "oval_execctx_new": (_int, [_cp, _vp, _sz, _i64, _i64, _i64, _i64, _i64, _i64, _pp, _cp, _sz]),
+    "oval_execctx_load": (_int, [_cp, _sz, _pp, _cp, _sz]),
+    "oval_execctx_load_file": (_int, [_cp, _pp, _cp, _sz]),
+    "oval_execctx_marshal": (_sz, [_vp, _vp, _sz]),
+    "oval_execctx_save_file": (_int, [_vp, _cp, _cp, _sz]),
+    "oval_execctx_destroy": (None, [_vp]),
+    "oval_execctx_info": (None, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
+                                 C.POINTER(_i64), C.POINTER(_sz), C.POINTER(_sz)]),
+    "oval_execctx_endpoint": (_sz, [_vp, _vp, _sz]),
+    "oval_execctx_worker_id": (_i64, [_vp, _sz]),
+    "oval_execctx_worker_buckets": (_sz, [_vp, _sz]),
+    "oval_execctx_bucket_name": (_sz, [_vp, _sz, _sz, _vp, _sz]),
+    "oval_execctx_objmeta": (_vp, [_vp, _sz, _sz]),
+    "oval_execctx_count_existing": (_u64, [_vp]),
+    "oval_objmeta_new": (_vp, [_i64, _i64]),
+    "oval_objmeta_free": (None, [_vp]),
+    "oval_objmeta_get_random_object": (_i64, [_vp]),
+    "oval_objmeta_register_to_existing_list": (_int, [_vp, _cp, _sz, _cp, _sz]),
+    "oval_objmeta_pop_existing_random_object": (_i64, [_vp]),
+    "oval_objmeta_get_existing_random_object": (_i64, [_vp]),
+    "oval_objmeta_exist": (_int, [_vp, _cp, _sz, C.POINTER(_int), _cp, _sz]),
+    "oval_objmeta_get_head_and_tail_key": (None, [_vp, _vp, _vp]),
+    "oval_objmeta_tidy_up": (_int, [_vp, _cp, _sz]),
+    "oval_objmeta_num_objects": (_sz, [_vp]),
+    "oval_objmeta_num_existing": (_sz, [_vp]),
+    "oval_objmeta_existing_id": (_i64, [_vp, _sz]),
+    "oval_objmeta_key_id_offset": (_i64, [_vp]),
+    "oval_objmeta_key_prefix": (_sz, [_vp, _vp, _sz]),
+    "oval_objmeta_get_object": (_int, [_vp, _i64, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "oval_objmeta_set_object": (_int, [_vp, _i64, _i64, _i64]),
+    "oval_object_seed_random": (None, [_u64]),
+    "oval_execctx_build_descs": (_int, [_vp, _u64, _sz, _sz, _vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64),
+                                        _cp, _sz]),
 }
 
 

@@ -1,0 +1,970 @@
+// oval_context.cpp — ObjectMeta, ExecutionContext (JSON in the reference's
+// format) and descriptor tables built from a context.  See oval_context.hpp.
+#include "oval_context.hpp"
+
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+namespace oval {
+
+// ---------------------------------------------------------------------------
+// rand.Intn
+// ---------------------------------------------------------------------------
+namespace {
+
+std::mutex g_rand_mu;
+uint64_t g_rand_state = 0x9E3779B97F4A7C15ull;
+
+uint64_t splitmix64()
+{
+    uint64_t z = (g_rand_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// uniform in [0, n), n > 0, without modulo bias
+int64_t rand_intn(int64_t n)
+{
+    std::lock_guard<std::mutex> lk(g_rand_mu);
+    const uint64_t un = (uint64_t)n;
+    const uint64_t limit = UINT64_MAX - (UINT64_MAX % un + 1) % un;
+    uint64_t x;
+    do x = splitmix64(); while (x > limit);
+    return (int64_t)(x % un);
+}
+
+}  // namespace
+
+namespace object {
+
+void SeedRandom(uint64_t seed)
+{
+    std::lock_guard<std::mutex> lk(g_rand_mu);
+    g_rand_state = seed;
+}
+
+std::pair<int64_t, Error> getObjIDFromKey(const std::string& key)
+{
+    // strconv.ParseInt(key[KeyPrefixLength:], 16, 64): an optional sign, then hex digits
+    if (key.size() <= (size_t)KeyPrefixLength)
+        return {0, Error::New("strconv.ParseInt: parsing \"" + (key.size() < (size_t)KeyPrefixLength ? std::string() : key.substr(KeyPrefixLength)) + "\": invalid syntax")};
+    const std::string s = key.substr(KeyPrefixLength);
+    size_t i = 0;
+    bool neg = false;
+    if (s[0] == '+' || s[0] == '-') { neg = s[0] == '-'; i = 1; }
+    if (i == s.size()) return {0, Error::New("strconv.ParseInt: parsing \"" + s + "\": invalid syntax")};
+    uint64_t v = 0;
+    for (; i < s.size(); ++i) {
+        const char c = s[i];
+        int d;
+        if (c >= '0' && c <= '9') d = c - '0';
+        else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+        else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+        else return {0, Error::New("strconv.ParseInt: parsing \"" + s + "\": invalid syntax")};
+        if (v >> 59) return {0, Error::New("strconv.ParseInt: parsing \"" + s + "\": value out of range")};
+        v = v * 16 + (uint64_t)d;
+    }
+    if (v > (uint64_t)INT64_MAX) return {0, Error::New("strconv.ParseInt: parsing \"" + s + "\": value out of range")};
+    return {neg ? -(int64_t)v : (int64_t)v, Error::Nil()};
+}
+
+ObjectMeta::ObjectMeta(int64_t numObj, int64_t keyIDOffset)
+{
+    if (numObj < 0) numObj = 0;
+    ObjectList.reserve((size_t)numObj);
+    for (int64_t objID = 0; objID < numObj; ++objID) ObjectList.push_back(NewObject(keyIDOffset + objID));
+    ExistingObjectIDs.reserve((size_t)std::sqrt((double)numObj));
+    existing_.assign((size_t)numObj, 0);
+    KeyIDOffset = keyIDOffset;
+    KeyPrefix = generateKey(keyIDOffset).substr(0, KeyPrefixLength);
+}
+
+Object* ObjectMeta::GetRandomObject()
+{
+    if (ObjectList.empty()) return nullptr;                      // rand.Intn(0) panics in the reference
+    return &ObjectList[(size_t)rand_intn((int64_t)ObjectList.size())];
+}
+
+Error ObjectMeta::RegisterToExistingList(const std::string& key)
+{
+    auto [objID, err] = getObjIDFromKey(key);
+    if (!err.nil()) return err;
+    if (objID < 0 || (uint64_t)objID >= ObjectList.size())
+        return Error::New("object ID of key " + key + " is outside this ObjectMeta's object list");
+    if (existing_[(size_t)objID]) return Error::Nil();           // The key is already registered.
+    ExistingObjectIDs.push_back(objID);
+    existing_[(size_t)objID] = 1;
+    if (ObjectList.size() < ExistingObjectIDs.size())
+        return Error::New("Invalid contents of existing object ID list.");
+    return Error::Nil();
+}
+
+Object* ObjectMeta::PopExistingRandomObject()
+{
+    if (ExistingObjectIDs.empty()) return nullptr;
+    const size_t idx = (size_t)rand_intn((int64_t)ExistingObjectIDs.size());
+    const int64_t objID = ExistingObjectIDs[idx];
+    // Delete the idx-th entry from the existing object ID list
+    ExistingObjectIDs[idx] = ExistingObjectIDs.back();
+    ExistingObjectIDs.pop_back();
+    existing_[(size_t)objID] = 0;
+    return &ObjectList[(size_t)objID];
+}
+
+Object* ObjectMeta::GetExistingRandomObject()
+{
+    if (ExistingObjectIDs.empty()) return nullptr;
+    const size_t idx = (size_t)rand_intn((int64_t)ExistingObjectIDs.size());
+    return &ObjectList[(size_t)ExistingObjectIDs[idx]];
+}
+
+std::pair<bool, Error> ObjectMeta::Exist(const std::string& key) const
+{
+    auto [objID, err] = getObjIDFromKey(key);
+    if (!err.nil()) return {false, err};
+    if (objID < 0 || (uint64_t)objID >= existing_.size()) return {false, Error::Nil()};
+    return {existing_[(size_t)objID] != 0, Error::Nil()};
+}
+
+std::pair<std::string, std::string> ObjectMeta::GetHeadAndTailKey() const
+{
+    if (ObjectList.empty()) return {std::string(), std::string()};
+    return {ObjectList.front().Key, ObjectList.back().Key};
+}
+
+Error ObjectMeta::TidyUp()
+{
+    existing_.assign(ObjectList.size(), 0);
+    for (int64_t objID : ExistingObjectIDs) {
+        if (objID < 0 || (uint64_t)objID >= ObjectList.size())
+            return Error::New("existingObjectIDs holds " + std::to_string(objID) + ", outside the object list of " +
+                              std::to_string(ObjectList.size()) + " objects");
+        existing_[(size_t)objID] = 1;
+    }
+    return Error::Nil();
+}
+
+}  // namespace object
+
+namespace runner {
+
+// ---------------------------------------------------------------------------
+// JSON input: a recursive-descent reader that fills the structs directly
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Reader {
+    const char* p;
+    const char* end;
+    const char* begin;
+    std::string err;
+
+    bool fail(const std::string& m)
+    {
+        if (err.empty()) err = m + " (at offset " + std::to_string((size_t)(p - begin)) + ")";
+        return false;
+    }
+    void ws()
+    {
+        while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) ++p;
+    }
+    bool lit(char c)
+    {
+        ws();
+        if (p < end && *p == c) { ++p; return true; }
+        return false;
+    }
+    bool expect(char c)
+    {
+        if (lit(c)) return true;
+        if (p >= end) return fail("unexpected end of JSON input");
+        return fail(std::string("invalid character, expected '") + c + "'");
+    }
+    bool word(const char* w)
+    {
+        const size_t n = std::strlen(w);
+        if ((size_t)(end - p) >= n && std::memcmp(p, w, n) == 0) { p += n; return true; }
+        return false;
+    }
+    bool null()
+    {
+        ws();
+        return word("null");
+    }
+
+    static void utf8(std::string& out, uint32_t c)
+    {
+        if (c < 0x80) out.push_back((char)c);
+        else if (c < 0x800) { out.push_back((char)(0xC0 | (c >> 6))); out.push_back((char)(0x80 | (c & 0x3F))); }
+        else if (c < 0x10000) {
+            out.push_back((char)(0xE0 | (c >> 12)));
+            out.push_back((char)(0x80 | ((c >> 6) & 0x3F)));
+            out.push_back((char)(0x80 | (c & 0x3F)));
+        } else {
+            out.push_back((char)(0xF0 | (c >> 18)));
+            out.push_back((char)(0x80 | ((c >> 12) & 0x3F)));
+            out.push_back((char)(0x80 | ((c >> 6) & 0x3F)));
+            out.push_back((char)(0x80 | (c & 0x3F)));
+        }
+    }
+    bool hex4(uint32_t& v)
+    {
+        if (end - p < 4) return fail("invalid \\u escape");
+        v = 0;
+        for (int i = 0; i < 4; ++i) {
+            const char c = *p++;
+            v <<= 4;
+            if (c >= '0' && c <= '9') v |= (uint32_t)(c - '0');
+            else if (c >= 'a' && c <= 'f') v |= (uint32_t)(c - 'a' + 10);
+            else if (c >= 'A' && c <= 'F') v |= (uint32_t)(c - 'A' + 10);
+            else return fail("invalid \\u escape");
+        }
+        return true;
+    }
+    bool string(std::string& out)
+    {
+        ws();
+        if (p >= end) return fail("unexpected end of JSON input");
+        if (*p != '"') return fail("invalid character, expected a string");
+        ++p;
+        out.clear();
+        while (p < end) {
+            const unsigned char c = (unsigned char)*p++;
+            if (c == '"') return true;
+            if (c < 0x20) return fail("invalid control character in string literal");
+            if (c != '\\') { out.push_back((char)c); continue; }
+            if (p >= end) break;
+            const char e = *p++;
+            switch (e) {
+            case '"': out.push_back('"'); break;
+            case '\\': out.push_back('\\'); break;
+            case '/': out.push_back('/'); break;
+            case 'b': out.push_back('\b'); break;
+            case 'f': out.push_back('\f'); break;
+            case 'n': out.push_back('\n'); break;
+            case 'r': out.push_back('\r'); break;
+            case 't': out.push_back('\t'); break;
+            case 'u': {
+                uint32_t u;
+                if (!hex4(u)) return false;
+                if (u >= 0xD800 && u < 0xDC00 && end - p >= 6 && p[0] == '\\' && p[1] == 'u') {
+                    const char* save = p;
+                    p += 2;
+                    uint32_t lo;
+                    if (!hex4(lo)) return false;
+                    if (lo >= 0xDC00 && lo < 0xE000) u = 0x10000 + ((u - 0xD800) << 10) + (lo - 0xDC00);
+                    else { p = save; u = 0xFFFD; }
+                } else if (u >= 0xD800 && u < 0xE000) {
+                    u = 0xFFFD;                                 // a lone surrogate decodes to U+FFFD
+                }
+                utf8(out, u);
+                break;
+            }
+            default: return fail("invalid escape in string literal");
+            }
+        }
+        return fail("unexpected end of JSON input");
+    }
+    // a JSON number destined for a Go int / int64
+    bool integer(int64_t& out, const char* field)
+    {
+        ws();
+        const char* s = p;
+        if (p < end && *p == '-') ++p;
+        if (p >= end || *p < '0' || *p > '9') { p = s; return fail(std::string("cannot unmarshal into field ") + field + " of type int"); }
+        while (p < end && *p >= '0' && *p <= '9') ++p;
+        if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) {
+            p = s;
+            return fail(std::string("cannot unmarshal a non-integer number into field ") + field + " of type int");
+        }
+        errno = 0;
+        const std::string t(s, (size_t)(p - s));
+        char* e = nullptr;
+        const long long v = std::strtoll(t.c_str(), &e, 10);
+        if (errno == ERANGE) { p = s; return fail(std::string("number ") + t + " overflows field " + field); }
+        out = (int64_t)v;
+        return true;
+    }
+    // skips any JSON value (an unknown field's)
+    bool skip(int depth = 0)
+    {
+        if (depth > 512) return fail("exceeded max depth");
+        ws();
+        if (p >= end) return fail("unexpected end of JSON input");
+        const char c = *p;
+        if (c == '"') { std::string t; return string(t); }
+        if (c == '{' || c == '[') {
+            const char close = c == '{' ? '}' : ']';
+            ++p;
+            if (lit(close)) return true;
+            for (;;) {
+                if (c == '{') {
+                    std::string k;
+                    if (!string(k) || !expect(':')) return false;
+                }
+                if (!skip(depth + 1)) return false;
+                if (lit(',')) continue;
+                return expect(close);
+            }
+        }
+        if (word("true") || word("false") || word("null")) return true;
+        if (c == '-' || (c >= '0' && c <= '9')) {
+            ++p;
+            while (p < end && ((*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) ++p;
+            return true;
+        }
+        return fail("invalid character looking for beginning of value");
+    }
+};
+
+// encoding/json matches field names exactly or under simple case folding
+bool key_is(const std::string& k, const char* name)
+{
+    const size_t n = std::strlen(name);
+    if (k.size() != n) return false;
+    for (size_t i = 0; i < n; ++i) {
+        char a = k[i], b = name[i];
+        if (a >= 'A' && a <= 'Z') a = (char)(a - 'A' + 'a');
+        if (b >= 'A' && b <= 'Z') b = (char)(b - 'A' + 'a');
+        if (a != b) return false;
+    }
+    return true;
+}
+
+// `{ "k": v, ... }` with one callback per member; the callback consumes v.
+template <class F>
+bool read_object(Reader& r, F member)
+{
+    if (!r.expect('{')) return false;
+    if (r.lit('}')) return true;
+    std::string k;
+    for (;;) {
+        if (!r.string(k) || !r.expect(':')) return false;
+        if (!member(k)) return false;
+        if (r.lit(',')) continue;
+        return r.expect('}');
+    }
+}
+
+// `[ v, ... ]` (or null = empty) with one callback per element
+template <class F>
+bool read_array(Reader& r, F element)
+{
+    if (r.null()) return true;
+    if (!r.expect('[')) return false;
+    if (r.lit(']')) return true;
+    for (;;) {
+        if (!element()) return false;
+        if (r.lit(',')) continue;
+        return r.expect(']');
+    }
+}
+
+bool read_string_field(Reader& r, std::string& dst)
+{
+    if (r.null()) return true;
+    return r.string(dst);
+}
+
+bool read_int_field(Reader& r, int64_t& dst, const char* name)
+{
+    if (r.null()) return true;
+    return r.integer(dst, name);
+}
+
+bool read_object_entry(Reader& r, object::Object& o)
+{
+    return read_object(r, [&](const std::string& k) {
+        if (key_is(k, "key")) return read_string_field(r, o.Key);
+        if (key_is(k, "size")) return read_int_field(r, o.Size, "Object.size");
+        if (key_is(k, "writeCount")) return read_int_field(r, o.WriteCount, "Object.writeCount");
+        return r.skip();
+    });
+}
+
+bool read_object_meta(Reader& r, object::ObjectMeta& om)
+{
+    return read_object(r, [&](const std::string& k) {
+        if (key_is(k, "objectList")) {
+            om.ObjectList.clear();
+            return read_array(r, [&] {
+                if (r.null()) return r.fail("objectList holds null: the reference would dereference a nil *Object");
+                om.ObjectList.emplace_back();
+                return read_object_entry(r, om.ObjectList.back());
+            });
+        }
+        if (key_is(k, "existingObjectIDs")) {
+            om.ExistingObjectIDs.clear();
+            return read_array(r, [&] {
+                int64_t v = 0;
+                if (!read_int_field(r, v, "ObjectMeta.existingObjectIDs")) return false;
+                om.ExistingObjectIDs.push_back(v);
+                return true;
+            });
+        }
+        if (key_is(k, "keyIDOffset")) return read_int_field(r, om.KeyIDOffset, "ObjectMeta.keyIDOffset");
+        if (key_is(k, "KeyPrefix")) return read_string_field(r, om.KeyPrefix);
+        return r.skip();
+    });
+}
+
+bool read_worker(Reader& r, Worker& w)
+{
+    return read_object(r, [&](const std::string& k) {
+        if (key_is(k, "bucketsWithObject")) {
+            w.BucketsWithObject.clear();
+            return read_array(r, [&] {
+                if (r.null()) return r.fail("bucketsWithObject holds null: the reference would dereference a nil *BucketWithObject");
+                w.BucketsWithObject.emplace_back();
+                BucketWithObject& b = w.BucketsWithObject.back();
+                return read_object(r, [&](const std::string& kk) {
+                    if (key_is(kk, "bucketName")) return read_string_field(r, b.BucketName);
+                    if (key_is(kk, "objectMeta")) {
+                        if (r.null()) return r.fail("objectMeta is null: the reference would dereference a nil *ObjectMeta");
+                        return read_object_meta(r, b.ObjectMeta);
+                    }
+                    return r.skip();
+                });
+            });
+        }
+        return r.skip();
+    });
+}
+
+// ---------------------------------------------------------------------------
+// JSON output: encoding/json's compact form with its default HTML escaping
+// ---------------------------------------------------------------------------
+void put_string(std::string& out, const std::string& s)
+{
+    static const char* hex = "0123456789abcdef";
+    out.push_back('"');
+    for (size_t i = 0; i < s.size();) {
+        const unsigned char c = (unsigned char)s[i];
+        if (c < 0x80) {
+            if (c == '"' || c == '\\') { out.push_back('\\'); out.push_back((char)c); }
+            else if (c == '\n') out += "\\n";
+            else if (c == '\r') out += "\\r";
+            else if (c == '\t') out += "\\t";
+            else if (c < 0x20 || c == '<' || c == '>' || c == '&') {
+                out += "\\u00";
+                out.push_back(hex[c >> 4]);
+                out.push_back(hex[c & 0xF]);
+            } else out.push_back((char)c);
+            ++i;
+            continue;
+        }
+        // a multi-byte sequence: copy it if it is valid UTF-8, else U+FFFD for one byte
+        int n = 0;
+        uint32_t cp = 0;
+        if (c >= 0xC2 && c <= 0xDF) { n = 2; cp = c & 0x1F; }
+        else if (c >= 0xE0 && c <= 0xEF) { n = 3; cp = c & 0x0F; }
+        else if (c >= 0xF0 && c <= 0xF4) { n = 4; cp = c & 0x07; }
+        bool ok = n != 0 && i + (size_t)n <= s.size();
+        for (int k = 1; ok && k < n; ++k) {
+            const unsigned char d = (unsigned char)s[i + (size_t)k];
+            if ((d & 0xC0) != 0x80) ok = false;
+            cp = (cp << 6) | (d & 0x3F);
+        }
+        if (ok && ((n == 3 && (cp < 0x800 || (cp >= 0xD800 && cp < 0xE000))) || (n == 4 && (cp < 0x10000 || cp > 0x10FFFF))))
+            ok = false;
+        if (!ok) { out += "\\ufffd"; ++i; continue; }
+        if (cp == 0x2028 || cp == 0x2029) { out += cp == 0x2028 ? "\\u2028" : "\\u2029"; }
+        else out.append(s, i, (size_t)n);
+        i += (size_t)n;
+    }
+    out.push_back('"');
+}
+
+void put_int(std::string& out, int64_t v) { out += std::to_string(v); }
+
+}  // namespace
+
+std::string MarshalContext(const ExecutionContext& ec)
+{
+    std::string o;
+    o.reserve(256 + (size_t)CountExisting(ec) * 8);
+    o += "{\"endpoint\":";
+    put_string(o, ec.Endpoint);
+    o += ",\"bucketNames\":";
+    if (ec.BucketNames.empty()) o += "[]";
+    else {
+        o.push_back('[');
+        for (size_t i = 0; i < ec.BucketNames.size(); ++i) {
+            if (i) o.push_back(',');
+            put_string(o, ec.BucketNames[i]);
+        }
+        o.push_back(']');
+    }
+    o += ",\"numObj\":"; put_int(o, ec.NumObj);
+    o += ",\"numWorker\":"; put_int(o, ec.NumWorker);
+    o += ",\"minSize\":"; put_int(o, ec.MinSize);
+    o += ",\"maxSize\":"; put_int(o, ec.MaxSize);
+    o += ",\"startWorkerID\":"; put_int(o, ec.StartWorkerID);
+    o += ",\"workers\":[";
+    for (size_t w = 0; w < ec.Workers.size(); ++w) {
+        if (w) o.push_back(',');
+        o += "{\"bucketsWithObject\":[";
+        const Worker& wk = ec.Workers[w];
+        for (size_t b = 0; b < wk.BucketsWithObject.size(); ++b) {
+            if (b) o.push_back(',');
+            const BucketWithObject& bo = wk.BucketsWithObject[b];
+            o += "{\"bucketName\":";
+            put_string(o, bo.BucketName);
+            o += ",\"objectMeta\":{\"objectList\":[";
+            const object::ObjectMeta& om = bo.ObjectMeta;
+            for (size_t i = 0; i < om.ObjectList.size(); ++i) {
+                if (i) o.push_back(',');
+                o += "{\"key\":";
+                put_string(o, om.ObjectList[i].Key);
+                o += ",\"size\":"; put_int(o, om.ObjectList[i].Size);
+                o += ",\"writeCount\":"; put_int(o, om.ObjectList[i].WriteCount);
+                o.push_back('}');
+            }
+            o += "],\"existingObjectIDs\":[";
+            for (size_t i = 0; i < om.ExistingObjectIDs.size(); ++i) {
+                if (i) o.push_back(',');
+                put_int(o, om.ExistingObjectIDs[i]);
+            }
+            o += "],\"keyIDOffset\":"; put_int(o, om.KeyIDOffset);
+            o += ",\"KeyPrefix\":";
+            put_string(o, om.KeyPrefix);
+            o += "}}";
+        }
+        o += "]}";
+    }
+    o += "]}";
+    return o;
+}
+
+Error SaveContext(const ExecutionContext& ec, const std::string& path)
+{
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return Error::New("open " + path + ": " + std::strerror(errno));
+    const std::string data = MarshalContext(ec);
+    size_t off = 0;
+    while (off < data.size()) {
+        const size_t n = std::fwrite(data.data() + off, 1, data.size() - off, f);
+        if (n == 0) {
+            const std::string m = std::strerror(errno);
+            std::fclose(f);
+            return Error::New("write " + path + ": " + m);
+        }
+        off += n;
+    }
+    if (std::fclose(f) != 0) return Error::New("close " + path + ": " + std::strerror(errno));
+    return Error::Nil();
+}
+
+namespace {
+
+// the part of Runner.init that applies to a loaded or a fresh context alike
+// (runner.go:111-114)
+void stamp_workers(ExecutionContext& ec)
+{
+    for (size_t i = 0; i < ec.Workers.size(); ++i) {
+        ec.Workers[i].id = (ec.StartWorkerID + (int64_t)i) % maxWorkerID;
+        ec.Workers[i].minSize = ec.MinSize;
+        ec.Workers[i].maxSize = ec.MaxSize;
+    }
+}
+
+}  // namespace
+
+std::pair<ExecutionContext, Error> LoadSavedContext(const char* json, size_t len)
+{
+    ExecutionContext ec;
+    Reader r{json, json + len, json, std::string()};
+    if (r.null()) {
+        // json.Unmarshal of "null" into a struct pointer leaves the struct zero
+    } else {
+        const bool ok = read_object(r, [&](const std::string& k) {
+            if (key_is(k, "endpoint")) return read_string_field(r, ec.Endpoint);
+            if (key_is(k, "bucketNames")) {
+                ec.BucketNames.clear();
+                return read_array(r, [&] {
+                    ec.BucketNames.emplace_back();
+                    return read_string_field(r, ec.BucketNames.back());
+                });
+            }
+            if (key_is(k, "numObj")) return read_int_field(r, ec.NumObj, "ExecutionContext.numObj");
+            if (key_is(k, "numWorker")) return read_int_field(r, ec.NumWorker, "ExecutionContext.numWorker");
+            if (key_is(k, "minSize")) return read_int_field(r, ec.MinSize, "ExecutionContext.minSize");
+            if (key_is(k, "maxSize")) return read_int_field(r, ec.MaxSize, "ExecutionContext.maxSize");
+            if (key_is(k, "startWorkerID")) return read_int_field(r, ec.StartWorkerID, "ExecutionContext.startWorkerID");
+            if (key_is(k, "workers")) {
+                ec.Workers.clear();
+                return read_array(r, [&] {
+                    ec.Workers.emplace_back();
+                    return read_worker(r, ec.Workers.back());
+                });
+            }
+            return r.skip();
+        });
+        if (!ok) return {ExecutionContext(), Error::New("json: " + r.err)};
+    }
+    r.ws();
+    if (r.p != r.end) {
+        r.fail("invalid character after top-level value");
+        return {ExecutionContext(), Error::New("json: " + r.err)};
+    }
+    if (ec.BucketNames.empty()) return {ExecutionContext(), Error::New("bucket list is empty.")};   // runner.go:54-57
+    stamp_workers(ec);
+    for (Worker& w : ec.Workers)
+        for (BucketWithObject& b : w.BucketsWithObject) {
+            Error e = b.ObjectMeta.TidyUp();
+            if (!e.nil()) return {ExecutionContext(), e};
+        }
+    return {std::move(ec), Error::Nil()};
+}
+
+std::pair<ExecutionContext, Error> LoadSavedContextFile(const std::string& path)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return {ExecutionContext(), Error::New("open " + path + ": " + std::strerror(errno))};
+    std::string data;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
+    const bool bad = std::ferror(f) != 0;
+    std::fclose(f);
+    if (bad) return {ExecutionContext(), Error::New("read " + path + ": " + std::strerror(errno))};
+    return LoadSavedContext(data.data(), data.size());
+}
+
+std::pair<ExecutionContext, Error> NewExecutionContext(const std::string& endpoint,
+                                                       const std::vector<std::string>& bucketNames,
+                                                       int64_t numObj, int64_t numWorker, int64_t minSize,
+                                                       int64_t maxSize, int64_t startWorkerID, int64_t runnerID)
+{
+    if (bucketNames.empty()) return {ExecutionContext(), Error::New("bucket list is empty.")};     // runner.go:54-57
+    if (numWorker <= 0) return {ExecutionContext(), Error::New("numWorker must be positive")};
+    if (numObj < 0) return {ExecutionContext(), Error::New("numObj must not be negative")};
+    ExecutionContext ec;
+    ec.Endpoint = endpoint;
+    ec.BucketNames = bucketNames;
+    ec.NumObj = numObj;
+    ec.NumWorker = numWorker;
+    ec.MinSize = minSize;
+    ec.MaxSize = maxSize;
+    ec.StartWorkerID = startWorkerID >= 0 ? startWorkerID : rand_intn(maxWorkerID);
+    ec.Workers.resize((size_t)numWorker);
+    stamp_workers(ec);
+    for (int64_t i = 0; i < numWorker; ++i) {
+        Worker& w = ec.Workers[(size_t)i];
+        w.BucketsWithObject.reserve(bucketNames.size());
+        for (const std::string& name : bucketNames) {
+            w.BucketsWithObject.emplace_back();
+            w.BucketsWithObject.back().BucketName = name;
+            w.BucketsWithObject.back().ObjectMeta =
+                object::ObjectMeta(numObj / numWorker, (runnerID << 32) + (i << 24));
+        }
+    }
+    return {std::move(ec), Error::Nil()};
+}
+
+uint64_t CountExisting(const ExecutionContext& ec)
+{
+    uint64_t n = 0;
+    for (const Worker& w : ec.Workers)
+        for (const BucketWithObject& b : w.BucketsWithObject) n += b.ObjectMeta.ExistingObjectIDs.size();
+    return n;
+}
+
+std::pair<DescriptorTable, Error> BuildExistingDescriptors(const ExecutionContext& ec, uint64_t unixMicro,
+                                                           size_t workerBegin, size_t workerEnd)
+{
+    DescriptorTable t;
+    if (workerEnd > ec.Workers.size()) workerEnd = ec.Workers.size();
+    size_t n = 0;
+    for (size_t w = workerBegin; w < workerEnd; ++w)
+        for (const BucketWithObject& b : ec.Workers[w].BucketsWithObject) n += b.ObjectMeta.ExistingObjectIDs.size();
+    t.descs.reserve(n);
+    t.refs.reserve(n);
+    uint64_t off = 0;
+    for (size_t w = workerBegin; w < workerEnd; ++w) {
+        const Worker& wk = ec.Workers[w];
+        for (size_t b = 0; b < wk.BucketsWithObject.size(); ++b) {
+            const BucketWithObject& bo = wk.BucketsWithObject[b];
+            // Valid and Generate cut the bucket name to 16 bytes (pattern.go:74-76,119-121)
+            const std::string bucket = bo.BucketName.substr(0, object::MaxBucketNameLength);
+            for (int64_t objID : bo.ObjectMeta.ExistingObjectIDs) {
+                if (objID < 0 || (uint64_t)objID >= bo.ObjectMeta.ObjectList.size())
+                    return {DescriptorTable(), Error::New("existingObjectIDs holds " + std::to_string(objID) +
+                                                          ", outside the object list")};
+                const object::Object& obj = bo.ObjectMeta.ObjectList[(size_t)objID];
+                if (obj.Size < 0) return {DescriptorTable(), Error::New("object " + obj.Key + " has a negative size")};
+                const uint64_t units = (uint64_t)obj.Size / (uint64_t)pattern::dataUnitSize;
+                if (units > UINT32_MAX) return {DescriptorTable(), Error::New("object " + obj.Key + " is too large")};
+                oval_obj_desc d;
+                const int rc = oval_desc_init(&d, bucket.data(), bucket.size(), obj.Key.data(), obj.Key.size(),
+                                              obj.WriteCount, wk.id, unixMicro, off, 0, (uint32_t)units);
+                if (rc != OVAL_OK)
+                    return {DescriptorTable(), Error::New("object " + obj.Key + ": " + oval_last_error())};
+                t.descs.push_back(d);
+                t.refs.push_back(ObjectRef{(uint32_t)w, (uint32_t)b, objID});
+                off += units * (uint64_t)pattern::dataUnitSize;
+            }
+        }
+    }
+    t.bodyBytes = off;
+    return {std::move(t), Error::Nil()};
+}
+
+}  // namespace runner
+}  // namespace oval
+
+// ---------------------------------------------------------------------------
+// C entry points (include/oval_context.h)
+// ---------------------------------------------------------------------------
+#include "../../include/oval_context.h"
+
+struct oval_execctx {
+    oval::runner::ExecutionContext ec;
+};
+// An oval_objmeta* is an oval::object::ObjectMeta* (borrowed from a context, or
+// owned when it came from oval_objmeta_new).
+static inline oval::object::ObjectMeta* OM(oval_objmeta* p) { return reinterpret_cast<oval::object::ObjectMeta*>(p); }
+static inline const oval::object::ObjectMeta* OM(const oval_objmeta* p)
+{
+    return reinterpret_cast<const oval::object::ObjectMeta*>(p);
+}
+
+namespace {
+
+int put_err(const oval::Error& e, char* err, size_t cap)
+{
+    if (err && cap) err[0] = '\0';
+    if (e.nil()) return 0;
+    if (err && cap) {
+        const size_t n = e.msg.size() < cap - 1 ? e.msg.size() : cap - 1;
+        std::memcpy(err, e.msg.data(), n);
+        err[n] = '\0';
+    }
+    return 1;
+}
+
+size_t put_text(const std::string& s, char* out, size_t cap)
+{
+    if (out && cap) std::memcpy(out, s.data(), s.size() < cap ? s.size() : cap);
+    return s.size();
+}
+
+void put_key13(const std::string& k, char* out13)
+{
+    if (!out13) return;
+    const size_t n = k.size() < 12 ? k.size() : 12;
+    std::memcpy(out13, k.data(), n);
+    out13[n] = '\0';
+}
+
+int64_t index_of(const oval::object::ObjectMeta* om, const oval::object::Object* o)
+{
+    return o ? (int64_t)(o - om->ObjectList.data()) : -1;
+}
+
+int adopt(std::pair<oval::runner::ExecutionContext, oval::Error>&& r, oval_execctx** out, char* err, size_t cap)
+{
+    if (out) *out = nullptr;
+    if (!r.second.nil() || !out) return put_err(r.second.nil() ? oval::Error::New("out is NULL") : r.second, err, cap);
+    oval_execctx* h = new (std::nothrow) oval_execctx;
+    if (!h) return OVAL_E_NOMEM;
+    h->ec = std::move(r.first);
+    *out = h;
+    return put_err(oval::Error::Nil(), err, cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int oval_execctx_new(const char* endpoint, const char* const* bucket_names, size_t n_buckets, int64_t num_obj,
+                     int64_t num_worker, int64_t min_size, int64_t max_size, int64_t start_worker_id,
+                     int64_t runner_id, oval_execctx** out, char* err, size_t err_cap)
+{
+    std::vector<std::string> names;
+    for (size_t i = 0; i < n_buckets; ++i) names.emplace_back(bucket_names && bucket_names[i] ? bucket_names[i] : "");
+    return adopt(oval::runner::NewExecutionContext(endpoint ? endpoint : "", names, num_obj, num_worker, min_size,
+                                                   max_size, start_worker_id, runner_id),
+                 out, err, err_cap);
+}
+
+int oval_execctx_load(const char* json, size_t len, oval_execctx** out, char* err, size_t err_cap)
+{
+    return adopt(oval::runner::LoadSavedContext(json ? json : "", json ? len : 0), out, err, err_cap);
+}
+
+int oval_execctx_load_file(const char* path, oval_execctx** out, char* err, size_t err_cap)
+{
+    return adopt(oval::runner::LoadSavedContextFile(path ? path : ""), out, err, err_cap);
+}
+
+size_t oval_execctx_marshal(const oval_execctx* ec, char* out, size_t cap)
+{
+    if (!ec) return 0;
+    return put_text(oval::runner::MarshalContext(ec->ec), out, cap);
+}
+
+int oval_execctx_save_file(const oval_execctx* ec, const char* path, char* err, size_t err_cap)
+{
+    if (!ec || !path) return OVAL_E_INVALID;
+    return put_err(oval::runner::SaveContext(ec->ec, path), err, err_cap);
+}
+
+void oval_execctx_destroy(oval_execctx* ec) { delete ec; }
+
+void oval_execctx_info(const oval_execctx* ec, int64_t* num_obj, int64_t* num_worker, int64_t* min_size,
+                       int64_t* max_size, int64_t* start_worker_id, size_t* n_workers, size_t* n_bucket_names)
+{
+    if (!ec) return;
+    if (num_obj) *num_obj = ec->ec.NumObj;
+    if (num_worker) *num_worker = ec->ec.NumWorker;
+    if (min_size) *min_size = ec->ec.MinSize;
+    if (max_size) *max_size = ec->ec.MaxSize;
+    if (start_worker_id) *start_worker_id = ec->ec.StartWorkerID;
+    if (n_workers) *n_workers = ec->ec.Workers.size();
+    if (n_bucket_names) *n_bucket_names = ec->ec.BucketNames.size();
+}
+
+size_t oval_execctx_endpoint(const oval_execctx* ec, char* out, size_t cap)
+{
+    return ec ? put_text(ec->ec.Endpoint, out, cap) : 0;
+}
+
+int64_t oval_execctx_worker_id(const oval_execctx* ec, size_t worker)
+{
+    return ec && worker < ec->ec.Workers.size() ? ec->ec.Workers[worker].id : -1;
+}
+
+size_t oval_execctx_worker_buckets(const oval_execctx* ec, size_t worker)
+{
+    return ec && worker < ec->ec.Workers.size() ? ec->ec.Workers[worker].BucketsWithObject.size() : 0;
+}
+
+size_t oval_execctx_bucket_name(const oval_execctx* ec, size_t worker, size_t bucket, char* out, size_t cap)
+{
+    if (!ec || worker >= ec->ec.Workers.size() || bucket >= ec->ec.Workers[worker].BucketsWithObject.size()) return 0;
+    return put_text(ec->ec.Workers[worker].BucketsWithObject[bucket].BucketName, out, cap);
+}
+
+oval_objmeta* oval_execctx_objmeta(oval_execctx* ec, size_t worker, size_t bucket)
+{
+    if (!ec || worker >= ec->ec.Workers.size() || bucket >= ec->ec.Workers[worker].BucketsWithObject.size())
+        return nullptr;
+    return reinterpret_cast<oval_objmeta*>(&ec->ec.Workers[worker].BucketsWithObject[bucket].ObjectMeta);
+}
+
+uint64_t oval_execctx_count_existing(const oval_execctx* ec) { return ec ? oval::runner::CountExisting(ec->ec) : 0; }
+
+oval_objmeta* oval_objmeta_new(int64_t num_obj, int64_t key_id_offset)
+{
+    return reinterpret_cast<oval_objmeta*>(new (std::nothrow) oval::object::ObjectMeta(num_obj, key_id_offset));
+}
+
+void oval_objmeta_free(oval_objmeta* om) { delete OM(om); }
+
+int64_t oval_objmeta_get_random_object(oval_objmeta* om) { return om ? index_of(OM(om), OM(om)->GetRandomObject()) : -1; }
+
+int oval_objmeta_register_to_existing_list(oval_objmeta* om, const char* key, size_t key_len, char* err,
+                                           size_t err_cap)
+{
+    if (!om) return OVAL_E_INVALID;
+    return put_err(OM(om)->RegisterToExistingList(std::string(key ? key : "", key ? key_len : 0)), err, err_cap);
+}
+
+int64_t oval_objmeta_pop_existing_random_object(oval_objmeta* om)
+{
+    return om ? index_of(OM(om), OM(om)->PopExistingRandomObject()) : -1;
+}
+
+int64_t oval_objmeta_get_existing_random_object(oval_objmeta* om)
+{
+    return om ? index_of(OM(om), OM(om)->GetExistingRandomObject()) : -1;
+}
+
+int oval_objmeta_exist(const oval_objmeta* om, const char* key, size_t key_len, int* exists_out, char* err,
+                       size_t err_cap)
+{
+    if (!om) return OVAL_E_INVALID;
+    auto r = OM(om)->Exist(std::string(key ? key : "", key ? key_len : 0));
+    if (exists_out) *exists_out = r.first ? 1 : 0;
+    return put_err(r.second, err, err_cap);
+}
+
+void oval_objmeta_get_head_and_tail_key(const oval_objmeta* om, char* head13, char* tail13)
+{
+    if (!om) return;
+    auto r = OM(om)->GetHeadAndTailKey();
+    put_key13(r.first, head13);
+    put_key13(r.second, tail13);
+}
+
+int oval_objmeta_tidy_up(oval_objmeta* om, char* err, size_t err_cap)
+{
+    if (!om) return OVAL_E_INVALID;
+    return put_err(OM(om)->TidyUp(), err, err_cap);
+}
+
+size_t oval_objmeta_num_objects(const oval_objmeta* om) { return om ? OM(om)->ObjectList.size() : 0; }
+size_t oval_objmeta_num_existing(const oval_objmeta* om) { return om ? OM(om)->ExistingObjectIDs.size() : 0; }
+
+int64_t oval_objmeta_existing_id(const oval_objmeta* om, size_t i)
+{
+    return om && i < OM(om)->ExistingObjectIDs.size() ? OM(om)->ExistingObjectIDs[i] : -1;
+}
+
+int64_t oval_objmeta_key_id_offset(const oval_objmeta* om) { return om ? OM(om)->KeyIDOffset : 0; }
+
+size_t oval_objmeta_key_prefix(const oval_objmeta* om, char* out, size_t cap)
+{
+    return om ? put_text(OM(om)->KeyPrefix, out, cap) : 0;
+}
+
+int oval_objmeta_get_object(const oval_objmeta* om, int64_t index, char* key13, int64_t* size, int64_t* write_count)
+{
+    if (!om) return OVAL_E_INVALID;
+    if (index < 0 || (uint64_t)index >= OM(om)->ObjectList.size()) return OVAL_E_RANGE;
+    const oval::object::Object& o = OM(om)->ObjectList[(size_t)index];
+    put_key13(o.Key, key13);
+    if (size) *size = o.Size;
+    if (write_count) *write_count = o.WriteCount;
+    return OVAL_OK;
+}
+
+int oval_objmeta_set_object(oval_objmeta* om, int64_t index, int64_t size, int64_t write_count)
+{
+    if (!om) return OVAL_E_INVALID;
+    if (index < 0 || (uint64_t)index >= OM(om)->ObjectList.size()) return OVAL_E_RANGE;
+    OM(om)->ObjectList[(size_t)index].Size = size;
+    OM(om)->ObjectList[(size_t)index].WriteCount = write_count;
+    return OVAL_OK;
+}
+
+void oval_object_seed_random(uint64_t seed) { oval::object::SeedRandom(seed); }
+
+int oval_execctx_build_descs(const oval_execctx* ec, uint64_t unix_micro, size_t worker_begin, size_t worker_end,
+                             oval_obj_desc* descs_out, oval_obj_ref* refs_out, uint64_t cap, uint64_t* n_out,
+                             uint64_t* body_bytes_out, char* err, size_t err_cap)
+{
+    if (!ec) return OVAL_E_INVALID;
+    auto r = oval::runner::BuildExistingDescriptors(ec->ec, unix_micro, worker_begin, worker_end);
+    if (!r.second.nil()) return put_err(r.second, err, err_cap);
+    const oval::runner::DescriptorTable& t = r.first;
+    if (n_out) *n_out = t.descs.size();
+    if (body_bytes_out) *body_bytes_out = t.bodyBytes;
+    const size_t n = t.descs.size() < cap ? t.descs.size() : (size_t)cap;
+    if (descs_out && n) std::memcpy(descs_out, t.descs.data(), n * sizeof(oval_obj_desc));
+    if (refs_out)
+        for (size_t i = 0; i < n; ++i) {
+            refs_out[i].worker = t.refs[i].worker;
+            refs_out[i].bucket = t.refs[i].bucket;
+            refs_out[i].obj_id = t.refs[i].objID;
+        }
+    return put_err(oval::Error::Nil(), err, err_cap);
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+"""ObjectMeta and ExecutionContext (internal/object/object.go:27-139,
+internal/runner/runner.go:26-35,85-135,250-273) — host logic, no GPU.
+
+Pinned by the reference's own output where it has any: the worker key ranges
+and worker IDs of README.md:71-74 and README.md:215-218,229-232.  The JSON text
+has no fixture in the reference (no saved context is checked in); it is
+compared with an independent restatement of encoding/json's rules built on
+Python's json module: parity unpinned beyond the struct tags.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from oval_amd import context as X
+from oval_amd.batch import build_descs, make_keys
+
+T0 = 1709558129112997
+
+
+def go_json(obj) -> bytes:
+    """encoding/json.Marshal of plain data: compact, UTF-8 kept, HTML-safe."""
+    s = json.dumps(obj, separators=(",", ":"), ensure_ascii=False)
+    for a, b in (("<", "\\u003c"), (">", "\\u003e"), ("&", "\\u0026"), (" ", "\\u2028"), (" ", "\\u2029")):
+        s = s.replace(a, b)
+    return s.encode()
+
+
+def expected_tree(endpoint, buckets, num_obj, num_worker, lo, hi, start, runner_id, state=None):
+    """What Runner.init builds (runner.go:106-125), as plain data in struct order."""
+    per = num_obj // num_worker
+    workers = []
+    for w in range(num_worker):
+        bwo = []
+        for b, name in enumerate(buckets):
+            off = (runner_id << 32) + (w << 24)
+            objs = [{"key": "ov%010x" % (off + j), "size": 0, "writeCount": 0} for j in range(per)]
+            existing = []
+            if state and (w, b) in state:
+                for j, size, wc in state[(w, b)]:
+                    objs[j]["size"], objs[j]["writeCount"] = size, wc
+                    existing.append(j)
+            bwo.append({"bucketName": name,
+                        "objectMeta": {"objectList": objs, "existingObjectIDs": existing, "keyIDOffset": off,
+                                       "KeyPrefix": ("ov%010x" % off)[:6]}})
+        workers.append({"bucketsWithObject": bwo})
+    return {"endpoint": endpoint, "bucketNames": list(buckets), "numObj": num_obj, "numWorker": num_worker,
+            "minSize": lo, "maxSize": hi, "startWorkerID": start, "workers": workers}
+
+
+def test_fresh_context_has_the_readme_key_ranges():
+    # README.md:71-74 — --num_obj 1024 --num_worker 4, runner 0, first worker ID 0x614
+    ec = X.ExecutionContext.New("http://localhost:9000", ["test-bucket", "test-bucket2"], 1024, 4, 4096, 16384,
+                                startWorkerID=0x614, runnerID=0)
+    assert [w.id for w in ec.Workers] == [0x614, 0x615, 0x616, 0x617]
+    heads_tails = [w.BucketsWithObject[0].ObjectMeta.GetHeadAndTailKey() for w in ec.Workers]
+    assert heads_tails == [("ov0000000000", "ov00000000ff"), ("ov0001000000", "ov00010000ff"),
+                           ("ov0002000000", "ov00020000ff"), ("ov0003000000", "ov00030000ff")]
+    for w in ec.Workers:
+        assert [b.BucketName for b in w.BucketsWithObject] == ["test-bucket", "test-bucket2"]
+        assert (w.minSize, w.maxSize) == (4096, 16384)
+        # the key range is the same for all buckets (worker.go:33-34)
+        assert w.BucketsWithObject[1].ObjectMeta.GetHeadAndTailKey() == w.BucketsWithObject[0].ObjectMeta.GetHeadAndTailKey()
+        assert len(w.BucketsWithObject[0].ObjectMeta) == 256
+    assert ec.Workers[2].BucketsWithObject[0].ObjectMeta.KeyPrefix == "ov0002"
+    assert ec.CountExisting() == 0
+
+
+def test_worker_ids_wrap_and_runner_id_shifts_keys():
+    ec = X.ExecutionContext.New("e", ["b"], 6, 3, 256, 512, startWorkerID=0xFFFF, runnerID=0x2A)
+    assert [w.id for w in ec.Workers] == [0xFFFF, 0, 1]          # runner.go:112
+    om = ec.Workers[1].BucketsWithObject[0].ObjectMeta
+    assert om.KeyIDOffset == (0x2A << 32) + (1 << 24)            # runner.go:121-123
+    assert om.GetHeadAndTailKey() == ("ov2a01000000", "ov2a01000001")
+    # drawn at random when not given (runner.go:109)
+    ids = {X.ExecutionContext.New("e", ["b"], 2, 1, 256, 256).StartWorkerID for _ in range(8)}
+    assert all(0 <= i < X.maxWorkerID for i in ids) and len(ids) > 1
+
+
+def test_marshal_is_go_json():
+    buckets = ["test-bucket", "b<2>&\"q\"\\"]
+    ec = X.ExecutionContext.New("http://localhost:9000/é ", buckets, 4, 2, 4096, 16384,
+                                startWorkerID=65535, runnerID=1)
+    assert ec.Marshal() == go_json(expected_tree("http://localhost:9000/é ", buckets, 4, 2, 4096, 16384,
+                                                 65535, 1))
+    # with state: the worker's mutations (worker.go:82-84) and registrations show up
+    om = ec.Workers[1].BucketsWithObject[0].ObjectMeta
+    o = om.Object(1)
+    o.Size = 8192
+    o.WriteCount += 3
+    om.RegisterToExistingList(o.Key)
+    om.RegisterToExistingList(om.Object(0).Key)
+    om.Object(0).Size = 4096
+    om.Object(0).WriteCount = 1
+    tree = expected_tree("http://localhost:9000/é ", buckets, 4, 2, 4096, 16384, 65535, 1,
+                         state={(1, 0): [(1, 8192, 3), (0, 4096, 1)]})
+    assert ec.Marshal() == go_json(tree)
+    # control characters: \n \r \t short forms, the rest \u00XX
+    ec2 = X.ExecutionContext.New("a\nb\rc\td\x01e\x7f", ["b"], 1, 1, 256, 256, startWorkerID=0)
+    assert b'"endpoint":"a\\nb\\rc\\td\\u0001e\x7f"' in ec2.Marshal()
+
+
+def test_load_round_trip_and_save_file(tmp_path):
+    X.seed_random(11)
+    ec = X.ExecutionContext.New("http://s3:9000", ["bucket-a", "bucket-b"], 64, 4, 4096, 16384, startWorkerID=0x50E4)
+    for w in ec.Workers:
+        for b in w.BucketsWithObject:
+            for _ in range(10):
+                o = b.ObjectMeta.GetRandomObject()
+                o.Size = 4096 + 256 * (o.index % 5)
+                o.WriteCount += 1
+                b.ObjectMeta.RegisterToExistingList(o.Key)
+    text = ec.Marshal()
+    path = tmp_path / "test.json"
+    ec.SaveContext(str(path))
+    assert path.read_bytes() == text
+    for ec2 in (X.ExecutionContext.Load(text), X.ExecutionContext.LoadFile(str(path))):
+        assert ec2.Marshal() == text
+        assert [w.id for w in ec2.Workers] == [0x50E4, 0x50E5, 0x50E6, 0x50E7]      # README.md:229-232
+        assert ec2.CountExisting() == ec.CountExisting() > 0
+        # TidyUp rebuilt the membership set (runner.go:126-129)
+        for w, w2 in zip(ec.Workers, ec2.Workers):
+            for b, b2 in zip(w.BucketsWithObject, w2.BucketsWithObject):
+                ids = b.ObjectMeta.ExistingObjectIDs
+                assert b2.ObjectMeta.ExistingObjectIDs == ids
+                for j in range(len(b.ObjectMeta)):
+                    assert b2.ObjectMeta.Exist(b.ObjectMeta.Object(j).Key) == (j in ids)
+    # python's json agrees on the meaning of the text
+    tree = json.loads(text)
+    assert tree["startWorkerID"] == 0x50E4 and len(tree["workers"]) == 4
+    assert tree["workers"][3]["bucketsWithObject"][1]["objectMeta"]["KeyPrefix"] == "ov0003"
+
+
+def test_load_follows_encoding_json_rules():
+    text = b"""
+    { "EndPoint" : "x\\u00e9\\ud83d\\ude00\\n" , "unknown": {"a":[1,2,{"b":null}], "c":"}"},
+      "bucketnames": ["b1", "b\\u003c2"], "NUMOBJ": 2, "numWorker": 1, "minSize": null, "maxSize": 512,
+      "startWorkerID": 65535, "extra": 1.5e3,
+      "workers": [ { "bucketsWithObject": [ { "BUCKETNAME": "b1", "objectMeta": {
+            "existingObjectIDs": [1], "objectList": [ {"key":"ov0000000000","size":0,"writeCount":0},
+                                                      {"writeCount":7,"size":512,"key":"ov0000000001","x":[]} ],
+            "keyprefix": "ov0000", "keyIDOffset": 0 } } ] } ] }
+    """
+    ec = X.ExecutionContext.Load(text)
+    assert ec.Endpoint == "xé\U0001F600\n"
+    assert (ec.NumObj, ec.NumWorker, ec.MinSize, ec.MaxSize, ec.StartWorkerID) == (2, 1, 0, 512, 65535)
+    om = ec.Workers[0].BucketsWithObject[0].ObjectMeta
+    assert ec.Workers[0].id == 65535 and ec.Workers[0].maxSize == 512
+    o = om.Object(1)
+    assert (o.Key, o.Size, o.WriteCount) == ("ov0000000001", 512, 7)
+    assert om.Exist("ov0000000001") and not om.Exist("ov0000000000")
+    assert om.KeyPrefix == "ov0000"
+    out = json.loads(ec.Marshal())
+    assert out["bucketNames"] == ["b1", "b<2"] and out["endpoint"] == "xé\U0001F600\n"
+
+    for bad, what in [(b'{"bucketNames":["b"],"numObj":1.5}', "non-integer"),
+                      (b'{"bucketNames":["b"],"numObj":"3"}', "numObj"),
+                      (b'{"bucketNames":["b"]', "unexpected end of JSON input"),
+                      (b'{"bucketNames":["b"] "x":1}', "expected"),
+                      (b'{"bucketNames":["b"]} x', "after top-level"),
+                      (b'{"bucketNames":[]}', "bucket list is empty."),
+                      (b'{}', "bucket list is empty."),
+                      (b'{"bucketNames":["b"],"workers":[{"bucketsWithObject":[{"objectMeta":{"objectList":[null]}}]}]}', "nil"),
+                      (b'{"bucketNames":["b"],"workers":[{"bucketsWithObject":[{"objectMeta":{"objectList":[],"existingObjectIDs":[0]}}]}]}', "outside the object list"),
+                      (b'', "unexpected end of JSON input")]:
+        with pytest.raises(X.ContextError) as e:
+            X.ExecutionContext.Load(bad)
+        assert what in str(e.value), (bad, str(e.value))
+    with pytest.raises(X.ContextError):
+        X.ExecutionContext.LoadFile("/nonexistent/test.json")
+    with pytest.raises(X.ContextError):
+        X.ExecutionContext.New("e", [], 1, 1, 256, 256)
+
+
+def test_object_meta_bookkeeping():
+    X.seed_random(3)
+    om = X.NewObjectMeta(100, (5 << 32) + (2 << 24))
+    assert len(om) == 100 and om.KeyPrefix == "ov0502" and om.ExistingObjectIDs == []
+    assert om.GetHeadAndTailKey() == ("ov0502000000", "ov0502000063")
+    assert om.PopExistingRandomObject() is None and om.GetExistingRandomObject() is None      # object.go:95-97,113-115
+    picks = {om.GetRandomObject().index for _ in range(400)}
+    assert picks <= set(range(100)) and len(picks) > 80
+
+    for j in (7, 3, 99, 7, 3):                                   # duplicates are ignored (object.go:83-86)
+        om.RegisterToExistingList("ov0502%06x" % j)
+    assert om.ExistingObjectIDs == [7, 3, 99]
+    assert om.Exist("ov0502000063") and om.Exist("ov0502000007") and not om.Exist("ov0502000008")
+    # only the six hex digits behind the prefix count (object.go:52-55)
+    assert om.Exist("zzzzzz000003") and not om.Exist("ov0502ffffff")
+    assert {om.GetExistingRandomObject().index for _ in range(100)} == {3, 7, 99}
+    assert len(om.ExistingObjectIDs) == 3
+
+    popped = []
+    while True:
+        o = om.PopExistingRandomObject()
+        if o is None:
+            break
+        assert not om.Exist(o.Key)
+        popped.append(o.index)
+    assert sorted(popped) == [3, 7, 99] and om.ExistingObjectIDs == []
+
+    o = om.Object(5)
+    o.Size, o.WriteCount = 1024, 9
+    assert repr(o) == "&{ov0502000005 1024 9}"                   # how worker.go:99 prints obj
+    o.Clear()
+    assert (o.Size, o.WriteCount) == (0, 0)
+
+    for bad in ("ov0502", "ov0502xyz", "short", "ov0502-"):
+        with pytest.raises(X.ContextError) as e:
+            om.Exist(bad)
+        assert "strconv.ParseInt" in str(e.value)
+    with pytest.raises(X.ContextError):
+        om.RegisterToExistingList("ov0502000064")                # ID 100 of a 100-object list
+    with pytest.raises(IndexError):
+        om.Object(100)
+
+
+def test_pop_is_uniform_swap_with_last():
+    # object.go:102-104: the popped slot is refilled with the last ID
+    X.seed_random(1)
+    om = X.NewObjectMeta(16, 0)
+    for j in range(16):
+        om.RegisterToExistingList("ov0000%06x" % j)
+    before = om.ExistingObjectIDs
+    o = om.PopExistingRandomObject()
+    after = om.ExistingObjectIDs
+    i = before.index(o.index)
+    expect = before[:-1]
+    if i < len(expect):
+        expect[i] = before[-1]
+    assert after == expect
+
+
+def test_existing_descriptors_match_build_descs():
+    X.seed_random(5)
+    ec = X.ExecutionContext.New("e", ["test-bucket", "a-bucket-name-longer-than-16"], 40, 4, 256, 4096,
+                                startWorkerID=0xFFFE, runnerID=1)
+    rng = np.random.default_rng(0)
+    for w in ec.Workers:
+        for b in w.BucketsWithObject:
+            for _ in range(6):
+                o = b.ObjectMeta.GetRandomObject()
+                o.Size = int(rng.integers(1, 17)) * 256
+                o.WriteCount += 1
+                b.ObjectMeta.RegisterToExistingList(o.Key)
+    descs, refs, nbytes = ec.BuildExistingDescriptors(T0)
+    assert len(descs) == len(refs) == ec.CountExisting()
+    # the same table from the Python builders, bucket by bucket
+    off = 0
+    k = 0
+    for wi, w in enumerate(ec.Workers):
+        for bi, b in enumerate(w.BucketsWithObject):
+            ids = b.ObjectMeta.ExistingObjectIDs
+            objs = [b.ObjectMeta.Object(j) for j in ids]
+            d = build_descs(b.BucketName, [o.Key for o in objs], [o.WriteCount for o in objs], w.id, T0,
+                            [o.Size for o in objs])
+            d["body_offset"] += np.uint64(off)
+            got = descs[k:k + len(ids)]
+            assert got.tobytes() == d.tobytes()
+            assert (refs["worker"][k:k + len(ids)] == wi).all() and (refs["bucket"][k:k + len(ids)] == bi).all()
+            assert refs["obj_id"][k:k + len(ids)].tolist() == ids
+            off += int(sum(o.Size for o in objs))
+            k += len(ids)
+    assert nbytes == off
+    # a rank's share (workers [1,3)) is the matching slice, rebased to offset 0
+    d13, r13, n13 = ec.BuildExistingDescriptors(T0, 1, 3)
+    sel = (refs["worker"] >= 1) & (refs["worker"] < 3)
+    assert r13.tobytes() == refs[sel].tobytes()
+    base = descs["body_offset"][sel][0]
+    assert (d13["body_offset"] == descs["body_offset"][sel] - base).all()
+    assert n13 == int((descs["n_units"][sel].astype(np.int64) * 256).sum())

@@ -18,7 +18,7 @@ T0 = 1709558129112997
 
 def _declared_functions():
     names = []
-    for h in ("oval_hip.h", "oval_pattern.h"):
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names += re.findall(r"\b(oval_[a-z0-9_]+)\s*\(", text)
