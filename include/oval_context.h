@@ -85,6 +85,13 @@ int oval_objmeta_set_object(oval_objmeta* om, int64_t index, int64_t size, int64
 /* seeds the source of rand.Intn behind the random picks */
 void oval_object_seed_random(uint64_t seed);
 
+/* The state a run leaves behind, without running one (no counterpart in the
+ * reference): every object exists with probability `fraction`, Size =
+ * DecideSize(MinSize, MaxSize) — pattern.go:22-71 — and WriteCount uniform in
+ * [1, max_write_count], from a generator seeded with `seed`. */
+int oval_execctx_populate(oval_execctx* ec, uint64_t seed, double fraction, int64_t max_write_count,
+                          char* err, size_t err_cap);
+
 /* ---- descriptor table of the existing objects ----------------------------- */
 typedef struct oval_obj_ref {
     uint32_t worker;   /* index into the context's workers */

@@ -141,6 +141,7 @@ SIGNATURES = {
     "oval_objmeta_get_object": (_int, [_vp, _i64, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "oval_objmeta_set_object": (_int, [_vp, _i64, _i64, _i64]),
     "oval_object_seed_random": (None, [_u64]),
+    "oval_execctx_populate": (_int, [_vp, _u64, C.c_double, _i64, _cp, _sz]),
     "oval_execctx_build_descs": (_int, [_vp, _u64, _sz, _sz, _vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64),
                                         _cp, _sz]),
 }

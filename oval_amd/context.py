@@ -252,6 +252,11 @@ class ExecutionContext:
     def CountExisting(self) -> int:
         return _lib.lib().oval_execctx_count_existing(self._h)
 
+    def PopulateExisting(self, seed: int, fraction: float = 1.0, max_write_count: int = 1000) -> None:
+        """Every object exists with probability `fraction`, sized by DecideSize."""
+        err = C.create_string_buffer(_ERR_CAP)
+        _raise(_lib.lib().oval_execctx_populate(self._h, seed, fraction, max_write_count, err, _ERR_CAP), err)
+
     def BuildExistingDescriptors(self, unix_micro: int, worker_begin: int = 0, worker_end: int = None):
         """(descs, refs, body_bytes): one descriptor per object that exists, for
         workers [worker_begin, worker_end), bodies back to back from offset 0."""

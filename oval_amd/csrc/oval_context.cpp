@@ -675,6 +675,34 @@ uint64_t CountExisting(const ExecutionContext& ec)
     return n;
 }
 
+Error PopulateExisting(ExecutionContext& ec, uint64_t seed, double fraction, int64_t maxWriteCount)
+{
+    if (maxWriteCount < 1) return Error::New("maxWriteCount must be at least 1");
+    uint64_t state = seed;
+    auto next = [&state]() {
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    auto unit = [&next]() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); };   // [0,1), 53 bits
+    for (Worker& w : ec.Workers)
+        for (BucketWithObject& b : w.BucketsWithObject) {
+            object::ObjectMeta& om = b.ObjectMeta;
+            for (size_t j = 0; j < om.ObjectList.size(); ++j) {
+                if (!(unit() < fraction)) continue;
+                auto size = pattern::DecideSizeFrom(ec.MinSize, ec.MaxSize, unit());
+                if (!size.second.nil()) return size.second;
+                object::Object& o = om.ObjectList[j];
+                o.Size = size.first;
+                o.WriteCount = 1 + (int64_t)(next() % (uint64_t)maxWriteCount);
+                Error e = om.RegisterToExistingList(o.Key);
+                if (!e.nil()) return e;
+            }
+        }
+    return Error::Nil();
+}
+
 std::pair<DescriptorTable, Error> BuildExistingDescriptors(const ExecutionContext& ec, uint64_t unixMicro,
                                                            size_t workerBegin, size_t workerEnd)
 {
@@ -945,6 +973,13 @@ int oval_objmeta_set_object(oval_objmeta* om, int64_t index, int64_t size, int64
 }
 
 void oval_object_seed_random(uint64_t seed) { oval::object::SeedRandom(seed); }
+
+int oval_execctx_populate(oval_execctx* ec, uint64_t seed, double fraction, int64_t max_write_count, char* err,
+                          size_t err_cap)
+{
+    if (!ec) return OVAL_E_INVALID;
+    return put_err(oval::runner::PopulateExisting(ec->ec, seed, fraction, max_write_count), err, err_cap);
+}
 
 int oval_execctx_build_descs(const oval_execctx* ec, uint64_t unix_micro, size_t worker_begin, size_t worker_end,
                              oval_obj_desc* descs_out, oval_obj_ref* refs_out, uint64_t cap, uint64_t* n_out,

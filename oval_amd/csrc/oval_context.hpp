@@ -116,5 +116,12 @@ std::pair<DescriptorTable, Error> BuildExistingDescriptors(const ExecutionContex
                                                            size_t workerBegin, size_t workerEnd);
 uint64_t CountExisting(const ExecutionContext& ec);
 
+// Puts a context into the state a run leaves behind, without running one: every
+// object exists with probability `fraction`, with Size = DecideSize(MinSize,
+// MaxSize) (pattern.go:22-71) and WriteCount uniform in [1, maxWriteCount], from
+// a generator seeded with `seed`.  The source of synthetic batches shaped like
+// the reference's (worker.go:77-84).
+Error PopulateExisting(ExecutionContext& ec, uint64_t seed, double fraction, int64_t maxWriteCount);
+
 }  // namespace runner
 }  // namespace oval

@@ -269,3 +269,23 @@ def test_existing_descriptors_match_build_descs():
     base = descs["body_offset"][sel][0]
     assert (d13["body_offset"] == descs["body_offset"][sel] - base).all()
     assert n13 == int((descs["n_units"][sel].astype(np.int64) * 256).sum())
+
+
+def test_populate_existing_is_seeded_and_decide_size_shaped():
+    def make(seed, frac):
+        ec = X.ExecutionContext.New("e", ["b1", "b2"], 4000, 4, 4096, 16384, startWorkerID=7)
+        ec.PopulateExisting(seed, frac, 1000)
+        return ec
+    a, b, c = make(9, 0.5), make(9, 0.5), make(10, 0.5)
+    assert a.Marshal() == b.Marshal() != c.Marshal()
+    n = a.CountExisting()
+    assert 0.45 * 8000 < n < 0.55 * 8000
+    descs, refs, nbytes = a.BuildExistingDescriptors(T0)
+    sizes = descs["n_units"].astype(np.int64) * 256
+    assert sizes.min() >= 4096 and sizes.max() <= 16384 + 256      # the reference's own upper quirk included
+    assert 1 <= descs["write_count"].min() and descs["write_count"].max() <= 1000
+    assert 8500 < sizes.mean() < 10500                             # ~9.5 KB mean for 4k-16k
+    full = make(1, 1.0)
+    assert full.CountExisting() == 8000
+    with pytest.raises(X.ContextError):
+        full.PopulateExisting(1, 1.0, 0)
