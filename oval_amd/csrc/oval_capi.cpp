@@ -39,6 +39,11 @@ struct oval_ctx {
     int         fill_threads = 256;    // workgroup sizes of the two kernels
     int         validate_threads = 256;
     unsigned long long* tallies_dev = nullptr;   // striped bad-unit tallies of the validate kernels, zero between passes
+    // staging ring of the host-memory entry points, created on their first use
+    static constexpr int kRingSlots = 4;
+    void*       ring_dev = nullptr;                // kRingSlots slices
+    hipEvent_t  ring_ready[kRingSlots] = {};       // slot holds what its consumer waits for
+    hipEvent_t  ring_free[kRingSlots] = {};        // slot's consumer is done with it
 };
 
 struct oval_layout {
@@ -51,7 +56,7 @@ struct oval_layout {
     uint32_t  n_tiles = 0;
     bool      no_fill = false;   // some descriptor carries OVAL_DESC_NO_FILL
     uint64_t  cap_obj = 0;       // descriptors the device table can hold
-    uint32_t  cap_tiles = 0;    // entries the tile table can hold
+    uint32_t  cap_tiles = 0;    // tiles the chunk table has room for (kChunksPerTile entries each)
 };
 
 struct oval_timer {
@@ -188,6 +193,11 @@ int oval_ctx_destroy(oval_ctx* ctx)
     (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->tallies_dev) (void)hipFree(ctx->tallies_dev);
+    if (ctx->ring_dev) (void)hipFree(ctx->ring_dev);
+    for (int i = 0; i < oval_ctx::kRingSlots; ++i) {
+        if (ctx->ring_ready[i]) (void)hipEventDestroy(ctx->ring_ready[i]);
+        if (ctx->ring_free[i]) (void)hipEventDestroy(ctx->ring_free[i]);
+    }
     delete ctx;
     return OVAL_OK;
 }
@@ -465,13 +475,35 @@ int oval_read_unit(oval_ctx* ctx, const void* body_dev, uint64_t byte_offset, ui
 }
 
 // ---- bodies in host memory: stage through the device in slices -------------
-// A slice is a whole number of tiles (64 KiB each); the kernel for slice k runs
-// on the main stream while the copy of slice k-1 (fill) or k+1 (validate) runs
-// on the copy stream.
+// A slice is a whole number of tiles (64 KiB each) and lives in one slot of a
+// small ring of device memory owned by the context, so a call allocates
+// nothing of the size of the batch.  The kernel for slice k runs on the main
+// stream while the copies of its neighbours run on the copy stream.  A kernel
+// is handed `slot - slice_offset` as the body address: it addresses the body
+// by absolute offset, and exactly the offsets of its slice land in the slot.
 namespace {
 constexpr uint64_t kTileBytes = (uint64_t)oval::kUnitsPerTile * OVAL_UNIT_SIZE;
 constexpr uint32_t kSliceTiles = 512;   // 32 MiB
+constexpr uint64_t kSliceBytes = kSliceTiles * kTileBytes;
+
+hipError_t ensure_ring(oval_ctx* c)
+{
+    if (c->ring_dev) return hipSuccess;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < oval_ctx::kRingSlots && e == hipSuccess; ++i) {
+        if (!c->ring_ready[i]) e = hipEventCreateWithFlags(&c->ring_ready[i], hipEventDisableTiming);
+        if (e == hipSuccess && !c->ring_free[i]) e = hipEventCreateWithFlags(&c->ring_free[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipMalloc(&c->ring_dev, oval_ctx::kRingSlots * kSliceBytes);
+    return e;
 }
+
+// the body address that makes absolute offset b0 fall on the start of `slot`
+char* slot_base(const oval_ctx* c, uint32_t slot, uint64_t b0)
+{
+    return (char*)c->ring_dev + (uint64_t)slot * kSliceBytes - b0;
+}
+}  // namespace
 
 int oval_fill_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, void* body_host,
                          uint64_t body_bytes)
@@ -485,29 +517,34 @@ int oval_fill_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_o
         return fail(OVAL_E_RANGE, "host body holds %llu bytes but the layout spans %llu",
                     (unsigned long long)body_bytes, (unsigned long long)l->span_bytes);
     }
-    void* dev = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    hipError_t e = hipMalloc(&dev, l->span_bytes ? l->span_bytes : 256);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    if (l->no_fill) {
+        oval_layout_destroy(ctx, l);
+        return fail(OVAL_E_FIELD, "the batch holds an object whose names do not format to 28 bytes; "
+                                  "the reference's Generate fails for it (pattern.go:87-89)");
+    }
+    hipError_t e = ensure_ring(ctx);
     const uint32_t n_tiles = tiles_of(l);
     const oval::LayoutView v = view_of(l);
     uint32_t k = 0;
     for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles, ++k) {
         const uint32_t t1 = t0 + kSliceTiles < n_tiles ? t0 + kSliceTiles : n_tiles;
-        e = oval::launch_fill(ctx->stream, cfg_of(ctx), v, dev, t0, t1);
-        if (e == hipSuccess) e = hipEventRecord(ev[k & 1], ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ev[k & 1], 0);
+        const uint32_t slot = k % oval_ctx::kRingSlots;
         const uint64_t b0 = (uint64_t)t0 * kTileBytes;
         uint64_t b1 = (uint64_t)t1 * kTileBytes;
         if (b1 > l->span_bytes) b1 = l->span_bytes;
+        // the slot's previous slice must have left for the host
+        if (k >= (uint32_t)oval_ctx::kRingSlots) e = hipStreamWaitEvent(ctx->stream, ctx->ring_free[slot], 0);
+        if (e == hipSuccess) e = oval::launch_fill(ctx->stream, cfg_of(ctx), v, slot_base(ctx, slot, b0), t0, t1);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ring_ready[slot], ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ring_ready[slot], 0);
         if (e == hipSuccess && b1 > b0)
-            e = hipMemcpyAsync((char*)body_host + b0, (const char*)dev + b0, b1 - b0, hipMemcpyDeviceToHost,
+            e = hipMemcpyAsync((char*)body_host + b0, slot_base(ctx, slot, b0) + b0, b1 - b0, hipMemcpyDeviceToHost,
                                ctx->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ring_free[slot], ctx->copy_stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
-    for (int i = 0; i < 2; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
-    if (dev) (void)hipFree(dev);
+    const hipError_t e2 = hipStreamSynchronize(ctx->copy_stream);
+    if (e == hipSuccess) e = e2;
     oval_layout_destroy(ctx, l);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "fill_batch_host: %s", hipGetErrorString(e));
     return OVAL_OK;
@@ -526,33 +563,33 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
         return fail(OVAL_E_RANGE, "host body holds %llu bytes but the layout spans %llu",
                     (unsigned long long)body_bytes, (unsigned long long)l->span_bytes);
     }
-    void* dev = nullptr;
     oval_obj_result* res_dev = nullptr;
     unsigned long long* cnt_dev = nullptr;
-    std::vector<hipEvent_t> evs;
-    hipError_t e = hipMalloc(&dev, l->span_bytes ? l->span_bytes : 256);
+    hipError_t e = ensure_ring(ctx);
     if (e == hipSuccess) e = hipMalloc((void**)&res_dev, n_obj ? n_obj * sizeof(oval_obj_result) : 16);
     if (e == hipSuccess) e = hipMalloc((void**)&cnt_dev, OVAL_NUM_COUNTERS * 8);
     if (e == hipSuccess) e = hipMemsetAsync(cnt_dev, 0, OVAL_NUM_COUNTERS * 8, ctx->stream);
     const uint32_t n_tiles = tiles_of(l);
     const oval::LayoutView v = view_of(l);
     if (e == hipSuccess) e = oval::launch_init_results(ctx->stream, v, res_dev, cnt_dev);
-    for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles) {
+    uint32_t k = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles, ++k) {
         const uint32_t t1 = t0 + kSliceTiles < n_tiles ? t0 + kSliceTiles : n_tiles;
+        const uint32_t slot = k % oval_ctx::kRingSlots;
         const uint64_t b0 = (uint64_t)t0 * kTileBytes;
         uint64_t b1 = (uint64_t)t1 * kTileBytes;
         if (b1 > l->span_bytes) b1 = l->span_bytes;
-        hipEvent_t ev = nullptr;
-        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e != hipSuccess) break;
-        evs.push_back(ev);
-        if (b1 > b0)
-            e = hipMemcpyAsync((char*)dev + b0, (const char*)body_host + b0, b1 - b0, hipMemcpyHostToDevice,
-                               ctx->copy_stream);
-        if (e == hipSuccess) e = hipEventRecord(ev, ctx->copy_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
-        if (e == hipSuccess) e = oval::launch_validate(ctx->stream, cfg_of(ctx), v, dev, t0, t1, res_dev, cnt_dev,
-                                                       ctx->tallies_dev);
+        // the slot's previous slice must have been validated
+        if (k >= (uint32_t)oval_ctx::kRingSlots) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ring_free[slot], 0);
+        if (e == hipSuccess && b1 > b0)
+            e = hipMemcpyAsync(slot_base(ctx, slot, b0) + b0, (const char*)body_host + b0, b1 - b0,
+                               hipMemcpyHostToDevice, ctx->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ring_ready[slot], ctx->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ring_ready[slot], 0);
+        if (e == hipSuccess)
+            e = oval::launch_validate(ctx->stream, cfg_of(ctx), v, slot_base(ctx, slot, b0), t0, t1, res_dev, cnt_dev,
+                                      ctx->tallies_dev);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ring_free[slot], ctx->stream);
     }
     if (e == hipSuccess && n_obj)
         e = hipMemcpyAsync(results_host, res_dev, n_obj * sizeof(oval_obj_result), hipMemcpyDeviceToHost, ctx->stream);
@@ -560,8 +597,6 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
         e = hipMemcpyAsync(counters_host, cnt_dev, OVAL_NUM_COUNTERS * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->copy_stream);
-    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
-    if (dev) (void)hipFree(dev);
     if (res_dev) (void)hipFree(res_dev);
     if (cnt_dev) (void)hipFree(cnt_dev);
     oval_layout_destroy(ctx, l);
