@@ -104,12 +104,21 @@ def main():
     ap.add_argument("--validate-threads", type=int, default=0, help="workgroup size of the validate kernel")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--collective", default="torch", choices=["torch", "capi"],
+                    help="who runs the counter all-reduce: torch.distributed (default) or the library's own "
+                         "RCCL entry point oval_allreduce_counters (needs one GPU per rank)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to "
                     "rehearse more ranks than GPUs: ranks then share devices round-robin)")
     ap.add_argument("--sizes", default="", help="override object sizes, e.g. 65536-65536 (bytes, multiples of 256)")
     ap.add_argument("--batch-gib", type=float, default=64.0,
                     help="largest body buffer; a bigger workload runs as consecutive sub-batches through it")
     args = ap.parse_args()
+
+    # stdout carries the one JSON line and nothing else: libraries that print
+    # banners there (RCCL does on communicator creation) go to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -142,6 +151,13 @@ def main():
     ctx = engine.Context(local, stream.cuda_stream)
     ctx.set_tuning(args.fill_threads, args.validate_threads)
 
+    comm = None
+    if args.collective == "capi":
+        uid = [engine.Comm.unique_id() if rank == 0 else None]
+        if dist:
+            dist.broadcast_object_list(uid, src=0)
+        comm = engine.Comm(ctx, world, rank, uid[0])
+
     size_override = tuple(int(x) for x in args.sizes.split("-")) if args.sizes else None
     descs = build_batch(args.workload, rank, args.objects, args.seed, size_override)
     n_obj, units = len(descs), int(descs["n_units"].sum())
@@ -164,7 +180,10 @@ def main():
             if tv: tv.start()
             layout.validate(body, results[k], counters)
             if tv: tv.stop()
-        all_reduce_counters(counters)          # the one collective of a batch
+        if comm:                               # the one collective of a batch
+            comm.all_reduce_counters(counters)
+        else:
+            all_reduce_counters(counters)
 
     for _ in range(args.warmup):
         step()
@@ -218,7 +237,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][4]}", "objects_per_gpu": n_obj,
-                       "units_per_gpu": units, "bytes_per_gpu": nbytes, "sub_batches": len(parts), "sharding": "worker key range (process ID = rank)",
+                       "units_per_gpu": units, "bytes_per_gpu": nbytes, "sub_batches": len(parts), "sharding": "worker key range (process ID = rank)", "collective": args.collective,
                        "fill_threads": args.fill_threads or 256, "validate_threads": args.validate_threads or 256},
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
@@ -234,7 +253,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(descs, args.cpu_seconds / 2, cores)
             one = cpu_baseline(descs, args.cpu_seconds / 2, 1)
             out["cpu_baseline"]["single_thread_value"] = one["value"]
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if comm:
+        torch.cuda.synchronize()
+        comm.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

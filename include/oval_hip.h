@@ -213,6 +213,26 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs_host, uin
                              const void* body_host, uint64_t body_bytes,
                              oval_obj_result* results_host, uint64_t* counters_host);
 
+/* ---- the one collective -----------------------------------------------------
+ * Objects shard over GPUs by worker key range (internal/runner/runner.go:117-124:
+ * key ID = (runnerID << 32) + (worker << 24) + j), one process or thread and one
+ * context per GPU; the only thing that crosses GPUs is the sum of the counter
+ * vectors that oval_validate adds to.  The reference has no counterpart (its
+ * processes report to a leader over HTTP, internal/multiprocess).  RCCL is
+ * opened when the first of these functions is called, not when the library
+ * loads. */
+#define OVAL_COMM_ID_BYTES 128
+typedef struct oval_comm oval_comm;
+/* One rank creates the ID and hands the 128 bytes to the others by any means. */
+int oval_comm_unique_id(uint8_t* id_out);
+/* Collective over all ranks: every rank calls it with the same ID, with its
+ * context's device current. */
+int oval_comm_create(oval_ctx* ctx, int n_ranks, int rank, const uint8_t* id, oval_comm** out);
+int oval_comm_destroy(oval_comm* comm);
+/* counters_dev[0..n) = sum over all ranks, in place, asynchronously on the
+ * context's stream (ncclAllReduce, ncclUint64, ncclSum). */
+int oval_allreduce_counters(oval_ctx* ctx, oval_comm* comm, uint64_t* counters_dev, size_t n);
+
 /* ---- kernel launch tuning (benchmarks only) ------------------------------
  * Workgroup sizes of the fill and the validate kernel: 128, 256, 512 or 1024
  * threads; 0 restores the default (256, the fastest measured for both). */

@@ -84,6 +84,10 @@ SIGNATURES = {
     "oval_read_unit": (_int, [_vp, _vp, _u64, _vp]),
     "oval_fill_batch_host": (_int, [_vp, _vp, _u64, _vp, _u64]),
     "oval_validate_batch_host": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _vp]),
+    "oval_comm_unique_id": (_int, [_vp]),
+    "oval_comm_create": (_int, [_vp, _int, _int, _vp, _pp]),
+    "oval_comm_destroy": (_int, [_vp]),
+    "oval_allreduce_counters": (_int, [_vp, _vp, _vp, _sz]),
     "oval_timer_create": (_int, [_vp, _pp]),
     "oval_timer_destroy": (_int, [_vp]),
     "oval_timer_start": (_int, [_vp, _vp]),

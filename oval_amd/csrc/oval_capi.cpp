@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/oval_hip.h"
+#include "oval_capi_internal.h"
 #include "oval_kernels.h"
 #include "oval_gostr.h"
 #include "oval_trimspace.h"
@@ -77,6 +78,23 @@ int fail(int code, const char* fmt, ...)
     g_err = buf;
     return code;
 }
+
+}  // namespace
+
+int oval_internal_fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+int oval_internal_ctx_device(const oval_ctx* ctx) { return ctx->device; }
+hipStream_t oval_internal_ctx_stream(const oval_ctx* ctx) { return ctx->stream; }
+
+namespace {
 
 #define HIP_TRY(expr)                                                                    \
     do {                                                                                 \

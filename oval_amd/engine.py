@@ -172,6 +172,39 @@ def results_to_numpy(results, n_obj: int) -> np.ndarray:
     return out
 
 
+class Comm:
+    """RCCL communicator behind oval_allreduce_counters: one rank per GPU, the
+    batch counters are the only thing summed over ranks."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        check(_lib.lib().oval_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx: "Context", n_ranks: int, rank: int, uid: bytes):
+        if len(uid) != 128:
+            raise ValueError("the unique ID is 128 bytes")
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        check(_lib.lib().oval_comm_create(ctx.handle, n_ranks, rank, uid, C.byref(self._h)))
+
+    def all_reduce_counters(self, counters) -> None:
+        """counters: int64 CUDA tensor, summed over all ranks in place on the context's stream."""
+        check(_lib.lib().oval_allreduce_counters(self.ctx.handle, self._h, counters.data_ptr(), counters.numel()))
+
+    def close(self) -> None:
+        if self._h:
+            _lib.lib().oval_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Timer:
     """HIP events on the context's stream (oval_timer)."""
 
