@@ -220,15 +220,22 @@ def main():
         fill_gbs = 256.0 * units / (fill_ms / 1e3) / 1e9
         val_gbs = 256.0 * units / (val_ms / 1e3) / 1e9
         # kernel names as rocprofv3 reports them
-        fill_name = "fill_kernel<%d>" % (args.fill_threads or 256)
+        # the library gives objects that average under 256 KiB the one-level lookup
+        one_level = "true" if nbytes / max(n_obj, 1) < (256 << 10) else "false"
+        fill_name = "fill_kernel<%d, %s>" % (args.fill_threads or 256, one_level)
         val_name = "validate_kernel<%d>" % (args.validate_threads or 256)
-        dom, dom_ms, dom_gbs = (val_name, val_ms, val_gbs) if val_ms >= fill_ms else (fill_name, fill_ms, fill_gbs)
+        n_fill = sum(l.launches()[0] for l in layouts)
+        n_val = sum(l.launches()[1] for l in layouts)
+        dom, dom_ms, dom_gbs, dom_n = ((val_name, val_ms, val_gbs, n_val) if val_ms >= fill_ms
+                                       else (fill_name, fill_ms, fill_gbs, n_fill))
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 if not (args.objects or args.sizes):             # measured on the default shape only
-                    traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+                    # the file holds HBM bytes per pass over the batch (PMC passes); per launch here
+                    per_pass = json.load(open(tpath)).get(args.workload, {}).get(dom)
+                    traffic = per_pass // max(dom_n, 1) if per_pass else None
             except Exception:
                 traffic = None
         out = {
@@ -242,10 +249,13 @@ def main():
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": 256 * units // len(parts),
-                         "avg_launch_ms": round(dom_ms / len(parts), 4)},
+                         # a pass over the batch is `launches_per_step` equal launches of this kernel; the
+                         # HIP events bracket the pass, small helper kernels and launch gaps included
+                         "launches_per_step": dom_n, "algorithmic_bytes_per_launch": 256 * units // max(dom_n, 1),
+                         "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4)},
             "kernels": {"fill_ms": round(fill_ms, 4), "fill_GBps": round(fill_gbs, 1),
-                        "validate_ms": round(val_ms, 4), "validate_GBps": round(val_gbs, 1)},
+                        "validate_ms": round(val_ms, 4), "validate_GBps": round(val_gbs, 1),
+                        "fill_launches": n_fill, "validate_launches": n_val},
         }
         if world == 1 and args.cpu_seconds > 0:
             # all of this process's share of the host cores, and one core beside it

@@ -181,6 +181,11 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* layout, const oval_obj_desc* d
 int oval_layout_destroy(oval_ctx* ctx, oval_layout* layout);
 int oval_layout_info(const oval_layout* layout, uint64_t* n_obj, uint64_t* total_units,
                      uint64_t* span_bytes);
+/* How many launches of the fill and of the validate kernel one pass over the
+ * layout takes (a pass is cut where a launch would exceed the HIP grid limit
+ * or depend on more lookup-table bytes than stay cached); for callers that
+ * relate a profiler's per-launch durations to a pass. */
+int oval_layout_launches(const oval_layout* layout, uint32_t* fill_launches, uint32_t* validate_launches);
 
 /* ---- the two kernels ----------------------------------------------------
  * oval_fill: writes every unit of every object of the layout into body_dev

@@ -79,6 +79,7 @@ SIGNATURES = {
     "oval_layout_reset": (_int, [_vp, _vp, _vp, _u64]),
     "oval_layout_destroy": (_int, [_vp, _vp]),
     "oval_layout_info": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
+    "oval_layout_launches": (_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "oval_fill": (_int, [_vp, _vp, _vp, _u64]),
     "oval_validate": (_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "oval_read_unit": (_int, [_vp, _vp, _u64, _vp]),

@@ -51,6 +51,8 @@ struct oval_layout {
     int       device = 0;
     void*     descs_dev = nullptr;
     uint32_t* chunk_first_dev = nullptr;
+    void*     chunk_desc_dev = nullptr;   // per-chunk descriptor copies, only while `one_level`
+    bool      one_level = false;
     uint64_t  n_obj = 0;
     uint64_t  total_units = 0;
     uint64_t  span_bytes = 0;
@@ -58,6 +60,7 @@ struct oval_layout {
     bool      no_fill = false;   // some descriptor carries OVAL_DESC_NO_FILL
     uint64_t  cap_obj = 0;       // descriptors the device table can hold
     uint32_t  cap_tiles = 0;    // tiles the chunk table has room for (kChunksPerTile entries each)
+    uint32_t  cap_desc_tiles = 0;   // likewise for chunk_desc_dev
 };
 
 struct oval_timer {
@@ -109,6 +112,7 @@ oval::LayoutView view_of(const oval_layout* l)
     oval::LayoutView v;
     v.descs = l->descs_dev;
     v.chunk_first = l->chunk_first_dev;
+    v.chunk_desc = l->one_level ? l->chunk_desc_dev : nullptr;
     v.n_obj = (uint32_t)l->n_obj;
     v.n_tiles = l->n_tiles;
     v.span_units = (uint32_t)(l->span_bytes / OVAL_UNIT_SIZE);
@@ -394,6 +398,17 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
         HIP_TRY(hipMalloc((void**)&l->chunk_first_dev, (size_t)cap * oval::kChunksPerTile * 4));
         l->cap_tiles = cap;
     }
+    // Objects that average under 256 KiB get a 64-byte copy of its first object's
+    // descriptor per chunk (1.6 % of the body size): the fill then starts with one
+    // lookup instead of two dependent ones, worth 6-10 % on 4 KiB ... 64 KiB
+    // objects; for larger objects the extra table reads cost more than they save.
+    l->one_level = n_obj != 0 && span_bytes / n_obj < (256ull << 10);
+    if (l->one_level && (n_tiles > l->cap_desc_tiles || !l->chunk_desc_dev)) {
+        if (l->chunk_desc_dev) { (void)hipFree(l->chunk_desc_dev); l->chunk_desc_dev = nullptr; l->cap_desc_tiles = 0; }
+        const uint32_t cap = n_tiles ? n_tiles : 1;
+        HIP_TRY(hipMalloc(&l->chunk_desc_dev, (size_t)cap * oval::kChunksPerTile * sizeof(oval_obj_desc)));
+        l->cap_desc_tiles = cap;
+    }
     l->n_obj = n_obj;
     l->no_fill = no_fill;
     l->total_units = total_units;
@@ -401,7 +416,8 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
     l->n_tiles = n_tiles;
     if (n_obj)
         HIP_TRY(hipMemcpyAsync(l->descs_dev, descs, n_obj * sizeof(oval_obj_desc), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(oval::launch_build_chunk_table(ctx->stream, l->descs_dev, (uint32_t)n_obj, l->chunk_first_dev, n_tiles));
+    HIP_TRY(oval::launch_build_chunk_table(ctx->stream, l->descs_dev, (uint32_t)n_obj, l->chunk_first_dev,
+                                           l->one_level ? l->chunk_desc_dev : nullptr, n_tiles));
     // the caller's descriptor array may be pageable and is not retained: wait for the upload
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return OVAL_OK;
@@ -418,6 +434,7 @@ int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj
     if (rc) {
         if (l->descs_dev) (void)hipFree(l->descs_dev);
         if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
+        if (l->chunk_desc_dev) (void)hipFree(l->chunk_desc_dev);
         delete l;
         return rc;
     }
@@ -431,7 +448,21 @@ int oval_layout_destroy(oval_ctx* ctx, oval_layout* l)
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     if (l->descs_dev) (void)hipFree(l->descs_dev);
     if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
+    if (l->chunk_desc_dev) (void)hipFree(l->chunk_desc_dev);
     delete l;
+    return OVAL_OK;
+}
+
+int oval_layout_launches(const oval_layout* l, uint32_t* fill_launches, uint32_t* validate_launches)
+{
+    if (!l) return fail(OVAL_E_INVALID, "layout is NULL");
+    const uint32_t n = l->n_tiles;
+    if (fill_launches) {
+        const uint32_t per = oval::fill_tiles_per_launch(view_of(l), n);
+        *fill_launches = n && l->n_obj ? (n + per - 1) / per : 0;
+    }
+    if (validate_launches)
+        *validate_launches = n && l->n_obj ? (n + oval::kMaxTilesPerLaunch - 1) / oval::kMaxTilesPerLaunch : 0;
     return OVAL_OK;
 }
 

@@ -16,6 +16,7 @@ constexpr uint32_t kUnitsPerChunk = 16;                    // 4 KiB
 constexpr uint32_t kChunksPerTile = 16;
 constexpr uint32_t kUnitsPerTile  = kUnitsPerChunk * kChunksPerTile;   // 64 KiB
 constexpr uint32_t kMaxTilesPerLaunch = 1u << 19;          // 32 GiB of body per kernel launch
+constexpr uint64_t kWarmTableBudget = 32ull << 20;         // lookup-table bytes one fill launch may depend on
 
 // Bad-unit tallies are spread over this many copies of the counter vector, one
 // 128-byte line each, and folded into the caller's counters after the pass.
@@ -25,6 +26,7 @@ constexpr size_t   kTallyBytes   = (size_t)kTallyStripes * kTallyStride * 8;
 
 struct LayoutView {
     const void*     descs;        // oval_obj_desc[n_obj] in device memory
+    const void*     chunk_desc;   // [n_tiles * kChunksPerTile] 64-byte copy of that object's descriptor, or NULL
     const uint32_t* chunk_first;  // [n_tiles * kChunksPerTile] first object whose end lies beyond the chunk's first unit
     uint32_t        n_obj;
     uint32_t        n_tiles;
@@ -38,7 +40,11 @@ struct LaunchCfg {
 };
 
 hipError_t launch_build_chunk_table(hipStream_t s, const void* descs, uint32_t n_obj,
-                                    uint32_t* chunk_first, uint32_t n_tiles);
+                                    uint32_t* chunk_first, void* chunk_desc, uint32_t n_tiles);
+// Tiles one fill launch covers when `range` tiles are to be filled: bounded by
+// the HIP grid limit and by the lookup-table bytes a launch may depend on, and
+// chosen so that the launches of the range are of equal size.
+uint32_t fill_tiles_per_launch(const LayoutView& lv, uint32_t range);
 hipError_t launch_fill(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv, void* body,
                        uint32_t tile_begin, uint32_t tile_end);
 hipError_t launch_init_results(hipStream_t s, const LayoutView& lv, oval_obj_result* results,

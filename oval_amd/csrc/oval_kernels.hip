@@ -24,6 +24,10 @@
 // chunk table names the first object of the chunk, descriptors are fetched
 // with scalar loads (constant address space, one s_load_dwordx16 each), and a
 // wavefront walks forward only across the object boundaries inside its range.
+// The fill is sensitive to the latency of that lookup (one store per thread
+// means 8 MiB of body in flight per lookup), so for all but very large objects
+// it reads a per-chunk copy of the descriptor in parallel with the chunk table
+// entry instead of following it.
 //
 // Stores are non-temporal: a fill that leaves its lines dirty in L2 / Infinity
 // Cache makes the validate pass that follows pay for their write-back (measured:
@@ -50,11 +54,13 @@ __device__ __forceinline__ uint32_t reg_byte(const u32x4& v, int i)
 
 // ---------------------------------------------------------------------------
 // chunk table: chunk c (4 KiB = 16 units) -> first object whose end lies beyond
-// unit 16 c.  A 64 KiB tile starts at chunk 16 t.
+// unit 16 c, and (optionally) a copy of that object's descriptor.  A 64 KiB tile
+// starts at chunk 16 t.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void build_chunk_table_kernel(const u32x4* __restrict__ descs,
                                                                 uint32_t n_obj,
                                                                 uint32_t* __restrict__ chunk_first,
+                                                                u32x4* __restrict__ chunk_desc,
                                                                 uint32_t n_chunks)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,21 +74,26 @@ __global__ __launch_bounds__(256) void build_chunk_table_kernel(const u32x4* __r
         if (end > g) hi = mid; else lo = mid + 1;
     }
     chunk_first[t] = lo;
+    if (chunk_desc) {
+        const uint32_t oc = lo < n_obj ? lo : n_obj - 1u;
+        for (int q = 0; q < 4; ++q) chunk_desc[4u * t + q] = descs[4u * oc + q];
+    }
 }
 
 // ---------------------------------------------------------------------------
-// Reads the part of the chunk table and of the descriptor table that the
-// chunks [chunk_begin, chunk_end) refer to, so that it sits in the memory-side
-// cache when the pass over those chunks starts.  Every wavefront of a pass
-// starts with two dependent lookups (chunk table, descriptor); with 8 MiB of
-// body in flight per lookup latency, two cold HBM round trips under a saturated
-// write stream hold the fill at 3.3-4.8 TB/s where warm tables give 6.7-7.2
-// (the pre-pass itself costs under 1 %).  The validate kernel has its body loads
+// Reads the part of the chunk table, of the per-chunk descriptor copies (if
+// the layout has them) and of the descriptor table that the chunks
+// [chunk_begin, chunk_end) refer to, so that it sits in the memory-side cache
+// when the pass over those chunks starts.  Every wavefront of a pass starts
+// with a lookup; with 8 MiB of body in flight per lookup latency, cold HBM
+// round trips under a saturated write stream hold the fill at 3.3-4.8 TB/s
+// where warm tables give 6.9-7.2 (the pre-pass itself costs 1-2 %).  The validate kernel has its body loads
 // in flight while it looks up and does not need this (measured: no difference).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void warm_tables_kernel(const u32x4* __restrict__ descs,
                                                           const uint32_t* __restrict__ chunk_first,
-                                                          uint32_t n_obj, uint32_t chunk_begin, uint32_t chunk_end)
+                                                          uint32_t n_obj, uint32_t chunk_begin, uint32_t chunk_end,
+                                                          const u32x4* __restrict__ chunk_desc)
 {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -92,6 +103,13 @@ __global__ __launch_bounds__(256) void warm_tables_kernel(const u32x4* __restric
     for (uint32_t i = tid; i < (chunk_end - chunk_begin) / 4u; i += stride) {
         const u32x4 v = cf[i];
         acc |= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (chunk_desc) {
+        const u32x4* cd = chunk_desc + (size_t)chunk_begin * 4u;
+        for (uint32_t i = tid; i < (chunk_end - chunk_begin) * 4u; i += stride) {
+            const u32x4 v = cd[i];
+            acc |= v.x ^ v.y ^ v.z ^ v.w;
+        }
     }
     const uint32_t o_lo = chunk_first[chunk_begin];
     uint32_t o_hi = chunk_first[chunk_end - 1u] + kUnitsPerChunk + 1u;   // a chunk holds at most 16 objects
@@ -171,9 +189,9 @@ __device__ __forceinline__ uint32_t w_lane_force(const WObj& w, int j)
 // the chunk table and walks forward only across the object boundaries inside
 // its 1 KiB; units that belong to no object (gaps, the tail of the last tile)
 // are not written.
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void fill_kernel(sdesc_ptr descs, sidx_ptr chunk_first, uint32_t n_obj,
-                                                       u32x4* __restrict__ body, uint32_t unit_begin)
+template <int THREADS, bool ONE_LEVEL>
+__global__ __launch_bounds__(THREADS) void fill_kernel(sdesc_ptr descs, sidx_ptr chunk_first, sdesc_ptr chunk_desc,
+                                                       uint32_t n_obj, u32x4* __restrict__ body, uint32_t unit_begin)
 {
     const int lane = threadIdx.x & 63;
     const int j = lane & 15;
@@ -184,11 +202,25 @@ __global__ __launch_bounds__(THREADS) void fill_kernel(sdesc_ptr descs, sidx_ptr
     const uint32_t g4 = unit_begin + blockIdx.x * (THREADS / 16u) +
                         __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 4u;
     const uint32_t g = g4 + grp;
+    const uint32_t c = g4 / kUnitsPerChunk;
     WRaw r;
     WObj w;
-    w_fetch(descs, n_obj, chunk_first[g4 / kUnitsPerChunk], r);
+    if (ONE_LEVEL) {
+        // the chunk's own copy of its first object's descriptor: no dependent second load
+        const uint32_t o0 = chunk_first[c];
+        r.o = o0 < n_obj ? o0 : n_obj;
+        r.d0 = chunk_desc[4u * c];
+        r.d1 = chunk_desc[4u * c + 1u];
+        r.d2 = chunk_desc[4u * c + 2u];
+        r.d3 = chunk_desc[4u * c + 3u];
+    } else {
+        w_fetch(descs, n_obj, chunk_first[c], r);
+    }
     w_activate(r, n_obj, w);
     u32x4* const p = body + (size_t)g4 * 16u + (uint32_t)lane;
+    // Each part of the wavefront stores as soon as its object is known: settling
+    // all lanes first and storing once measured 2-3 % slower, a workgroup
+    // barrier before the store 4-8 %.
     for (;;) {
         if (g >= w.start && g < w.end) {
             u32x4 e = w_lane_template(w, j, cpat);
@@ -447,13 +479,26 @@ __global__ __launch_bounds__(256) void init_results_kernel(u32x4* __restrict__ r
 // launchers
 // ---------------------------------------------------------------------------
 hipError_t launch_build_chunk_table(hipStream_t s, const void* descs, uint32_t n_obj,
-                                    uint32_t* chunk_first, uint32_t n_tiles)
+                                    uint32_t* chunk_first, void* chunk_desc, uint32_t n_tiles)
 {
     if (n_tiles == 0) return hipSuccess;
     const uint32_t n_chunks = n_tiles * kChunksPerTile;
     const uint32_t blocks = (n_chunks + 255u) / 256u;
-    build_chunk_table_kernel<<<blocks, 256, 0, s>>>(static_cast<const u32x4*>(descs), n_obj, chunk_first, n_chunks);
+    build_chunk_table_kernel<<<blocks, 256, 0, s>>>(static_cast<const u32x4*>(descs), n_obj, chunk_first,
+                                                    static_cast<u32x4*>(chunk_desc), n_chunks);
     return hipGetLastError();
+}
+
+uint32_t fill_tiles_per_launch(const LayoutView& lv, uint32_t range)
+{
+    if (range == 0 || lv.n_tiles == 0) return 1;
+    const uint64_t table_bytes_per_tile =
+        kChunksPerTile * (4u + (lv.chunk_desc ? 64u : 0u)) + ((uint64_t)lv.n_obj * 64u + lv.n_tiles - 1u) / lv.n_tiles;
+    uint64_t max_tiles = kWarmTableBudget / table_bytes_per_tile;
+    if (max_tiles > kMaxTilesPerLaunch) max_tiles = kMaxTilesPerLaunch;
+    if (max_tiles < 1u) max_tiles = 1u;
+    const uint32_t n_launches = (uint32_t)((range + max_tiles - 1u) / max_tiles);
+    return (range + n_launches - 1u) / n_launches;
 }
 
 // A launch covers whole tiles; units of the last tile beyond the span map to
@@ -466,14 +511,26 @@ hipError_t launch_fill(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv
     sdesc_ptr sd = (sdesc_ptr)lv.descs;
     sidx_ptr cf = (sidx_ptr)lv.chunk_first;
     u32x4* b = static_cast<u32x4*>(body);
-    // One launch holds at most 2^31 threads (HIP refuses 2^32): 32 GiB of body for the fill.
-    for (uint32_t t0 = tile_begin; t0 < tile_end; t0 += kMaxTilesPerLaunch) {
-        const uint32_t t1 = tile_end - t0 > kMaxTilesPerLaunch ? t0 + kMaxTilesPerLaunch : tile_end;
+    sdesc_ptr cd = (sdesc_ptr)lv.chunk_desc;                    // NULL: two-level lookup
+    // One launch holds at most 2^31 threads (HIP refuses 2^32): 32 GiB of body for
+    // the fill.  It also covers no more body than its lookup tables, read by the
+    // pre-pass, stay in the memory-side cache for: a 38 GB batch of 4k-16k objects
+    // (0.9 GB of tables) filled at 4.65 TB/s in one launch and with 128 or 256 MB of
+    // tables per launch, at 6.8 with 64 MB, at 7.1 with 32 MB, at 7.0 with 16 MB.
+    // The range is cut into equal launches.
+    const uint32_t per_launch = fill_tiles_per_launch(lv, tile_end - tile_begin);
+    for (uint32_t t0 = tile_begin; t0 < tile_end; t0 += per_launch) {
+        const uint32_t t1 = tile_end - t0 > per_launch ? t0 + per_launch : tile_end;
         const uint32_t unit_begin = t0 * kUnitsPerTile;
         const uint32_t n_units = (t1 - t0) * kUnitsPerTile;
         warm_tables_kernel<<<1024, 256, 0, s>>>(static_cast<const u32x4*>(lv.descs), lv.chunk_first, lv.n_obj,
-                                                t0 * kChunksPerTile, t1 * kChunksPerTile);
-#define OVAL_LAUNCH_FILL(T) fill_kernel<T><<<n_units / (T / 16), T, 0, s>>>(sd, cf, lv.n_obj, b, unit_begin)
+                                                t0 * kChunksPerTile, t1 * kChunksPerTile,
+                                                static_cast<const u32x4*>(lv.chunk_desc));
+#define OVAL_LAUNCH_FILL(T)                                                                                    \
+    do {                                                                                                       \
+        if (cd) fill_kernel<T, true><<<n_units / (T / 16), T, 0, s>>>(sd, cf, cd, lv.n_obj, b, unit_begin);     \
+        else fill_kernel<T, false><<<n_units / (T / 16), T, 0, s>>>(sd, cf, cd, lv.n_obj, b, unit_begin);       \
+    } while (0)
         switch (cfg.fill_threads) {
         case 128: OVAL_LAUNCH_FILL(128); break;
         case 512: OVAL_LAUNCH_FILL(512); break;

@@ -110,6 +110,12 @@ class Layout:
         check(_lib.lib().oval_layout_info(self._h, C.byref(n), C.byref(u), C.byref(s)))
         self.n_obj, self.total_units, self.span_bytes = n.value, u.value, s.value
 
+    def launches(self):
+        """(fill, validate) kernel launches one pass over this layout takes."""
+        f, v = C.c_uint32(), C.c_uint32()
+        check(_lib.lib().oval_layout_launches(self._h, C.byref(f), C.byref(v)))
+        return f.value, v.value
+
     def reset(self, descs: np.ndarray) -> None:
         _check_descs(descs)
         check(_lib.lib().oval_layout_reset(self.ctx.handle, self._h, descs.ctypes.data, len(descs)))
