@@ -158,6 +158,27 @@ namespace runner {
 // ---------------------------------------------------------------------------
 namespace {
 
+// Length of the valid UTF-8 sequence at p (n bytes available), 0 if there is
+// none (utf8.DecodeRune's RuneError of width 1).
+int utf8_len(const char* p, size_t n, uint32_t& cp)
+{
+    const unsigned char c = (unsigned char)p[0];
+    int len = 0;
+    if (c < 0x80) { cp = c; return 1; }
+    if (c >= 0xC2 && c <= 0xDF) { len = 2; cp = c & 0x1Fu; }
+    else if (c >= 0xE0 && c <= 0xEF) { len = 3; cp = c & 0x0Fu; }
+    else if (c >= 0xF0 && c <= 0xF4) { len = 4; cp = c & 0x07u; }
+    if (len == 0 || (size_t)len > n) return 0;
+    for (int k = 1; k < len; ++k) {
+        const unsigned char d = (unsigned char)p[k];
+        if ((d & 0xC0) != 0x80) return 0;
+        cp = (cp << 6) | (d & 0x3Fu);
+    }
+    if (len == 3 && (cp < 0x800 || (cp >= 0xD800 && cp < 0xE000))) return 0;
+    if (len == 4 && (cp < 0x10000 || cp > 0x10FFFF)) return 0;
+    return len;
+}
+
 struct Reader {
     const char* p;
     const char* end;
@@ -237,6 +258,15 @@ struct Reader {
             const unsigned char c = (unsigned char)*p++;
             if (c == '"') return true;
             if (c < 0x20) return fail("invalid control character in string literal");
+            if (c >= 0x80) {
+                // encoding/json replaces invalid UTF-8 inside a string with U+FFFD
+                uint32_t cp;
+                const int len = utf8_len(p - 1, (size_t)(end - (p - 1)), cp);
+                if (len == 0) { out += "\xEF\xBF\xBD"; continue; }
+                out.append(p - 1, (size_t)len);
+                p += len - 1;
+                continue;
+            }
             if (c != '\\') { out.push_back((char)c); continue; }
             if (p >= end) break;
             const char e = *p++;
@@ -459,19 +489,9 @@ void put_string(std::string& out, const std::string& s)
             continue;
         }
         // a multi-byte sequence: copy it if it is valid UTF-8, else U+FFFD for one byte
-        int n = 0;
         uint32_t cp = 0;
-        if (c >= 0xC2 && c <= 0xDF) { n = 2; cp = c & 0x1F; }
-        else if (c >= 0xE0 && c <= 0xEF) { n = 3; cp = c & 0x0F; }
-        else if (c >= 0xF0 && c <= 0xF4) { n = 4; cp = c & 0x07; }
-        bool ok = n != 0 && i + (size_t)n <= s.size();
-        for (int k = 1; ok && k < n; ++k) {
-            const unsigned char d = (unsigned char)s[i + (size_t)k];
-            if ((d & 0xC0) != 0x80) ok = false;
-            cp = (cp << 6) | (d & 0x3F);
-        }
-        if (ok && ((n == 3 && (cp < 0x800 || (cp >= 0xD800 && cp < 0xE000))) || (n == 4 && (cp < 0x10000 || cp > 0x10FFFF))))
-            ok = false;
+        const int n = utf8_len(s.data() + i, s.size() - i, cp);
+        const bool ok = n != 0;
         if (!ok) { out += "\\ufffd"; ++i; continue; }
         if (cp == 0x2028 || cp == 0x2029) { out += cp == 0x2028 ? "\\u2028" : "\\u2029"; }
         else out.append(s, i, (size_t)n);

@@ -289,3 +289,12 @@ def test_populate_existing_is_seeded_and_decide_size_shaped():
     assert full.CountExisting() == 8000
     with pytest.raises(X.ContextError):
         full.PopulateExisting(1, 1.0, 0)
+
+
+def test_invalid_utf8_becomes_replacement_character():
+    # encoding/json: invalid UTF-8 inside a string decodes to U+FFFD, and Marshal writes invalid bytes as �
+    ec = X.ExecutionContext.Load(b'{"endpoint":"a\xffb\xc3(\xe2\x82","bucketNames":["b"]}')
+    assert ec.Endpoint == "a�b�(��"
+    assert b'"endpoint":"a\xef\xbf\xbdb\xef\xbf\xbd(\xef\xbf\xbd\xef\xbf\xbd"' in ec.Marshal()
+    ec2 = X.ExecutionContext.New(b"x\xffy", ["b"], 1, 1, 256, 256, startWorkerID=0)
+    assert b'"endpoint":"x\\ufffdy"' in ec2.Marshal()
