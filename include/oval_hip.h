@@ -166,12 +166,14 @@ int oval_desc_init(oval_obj_desc* d,
                    uint64_t body_offset, uint32_t first_unit, uint32_t n_units);
 
 /* ---- layout -------------------------------------------------------------
- * Uploads `n_obj` descriptors and builds the device-side tile index.
+ * Uploads `n_obj` descriptors and builds the device-side chunk index.
  * Requirements (checked; OVAL_E_LAYOUT otherwise): body_offset is a multiple
  * of 256 and bodies are in ascending, non-overlapping order (gaps and
  * zero-unit objects are allowed).  The layout can be used for any number of
  * fill / validate passes and owns all device memory it needs, so those passes
- * allocate nothing. */
+ * allocate nothing.  The descriptor array is copied before the call returns;
+ * the upload and the index build run asynchronously on the context's stream,
+ * and a pass issued through another context of the same device waits for them. */
 int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs_host, uint64_t n_obj,
                        oval_layout** out);
 /* Replaces the contents of an existing layout with a new descriptor set,

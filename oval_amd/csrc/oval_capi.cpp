@@ -61,6 +61,10 @@ struct oval_layout {
     uint64_t  cap_obj = 0;       // descriptors the device table can hold
     uint32_t  cap_tiles = 0;    // tiles the chunk table has room for (kChunksPerTile entries each)
     uint32_t  cap_desc_tiles = 0;   // likewise for chunk_desc_dev
+    void*     stage_host = nullptr; // pinned copy of the caller's descriptors on their way to the device
+    uint64_t  cap_stage = 0;        // descriptors it holds
+    hipStream_t built_on = nullptr; // stream the tables were last built on ...
+    hipEvent_t  built_ev = nullptr; // ... and the event that says they are complete
 };
 
 struct oval_timer {
@@ -414,12 +418,32 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
     l->total_units = total_units;
     l->span_bytes = span_bytes;
     l->n_tiles = n_tiles;
-    if (n_obj)
-        HIP_TRY(hipMemcpyAsync(l->descs_dev, descs, n_obj * sizeof(oval_obj_desc), hipMemcpyHostToDevice, ctx->stream));
+    // The caller's array is not retained and may be pageable: it is copied to a
+    // pinned buffer of the layout's here, and goes to the device from there in
+    // stream order, so this call does not wait for the device.  (The buffer's
+    // previous contents are out of use: the stream was drained above.)
+    if (n_obj) {
+        if (n_obj > l->cap_stage) {
+            if (l->stage_host) { (void)hipHostFree(l->stage_host); l->stage_host = nullptr; l->cap_stage = 0; }
+            HIP_TRY(hipHostMalloc(&l->stage_host, n_obj * sizeof(oval_obj_desc), hipHostMallocDefault));
+            l->cap_stage = n_obj;
+        }
+        std::memcpy(l->stage_host, descs, n_obj * sizeof(oval_obj_desc));
+        HIP_TRY(hipMemcpyAsync(l->descs_dev, l->stage_host, n_obj * sizeof(oval_obj_desc), hipMemcpyHostToDevice,
+                               ctx->stream));
+    }
     HIP_TRY(oval::launch_build_chunk_table(ctx->stream, l->descs_dev, (uint32_t)n_obj, l->chunk_first_dev,
                                            l->one_level ? l->chunk_desc_dev : nullptr, n_tiles));
-    // the caller's descriptor array may be pageable and is not retained: wait for the upload
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!l->built_ev) HIP_TRY(hipEventCreateWithFlags(&l->built_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(l->built_ev, ctx->stream));
+    l->built_on = ctx->stream;
+    return OVAL_OK;
+}
+
+// A pass on another stream than the one the tables were built on waits for them.
+static int await_tables(oval_ctx* ctx, const oval_layout* l)
+{
+    if (l->built_ev && l->built_on != ctx->stream) HIP_TRY(hipStreamWaitEvent(ctx->stream, l->built_ev, 0));
     return OVAL_OK;
 }
 
@@ -435,6 +459,8 @@ int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj
         if (l->descs_dev) (void)hipFree(l->descs_dev);
         if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
         if (l->chunk_desc_dev) (void)hipFree(l->chunk_desc_dev);
+        if (l->stage_host) (void)hipHostFree(l->stage_host);
+        if (l->built_ev) (void)hipEventDestroy(l->built_ev);
         delete l;
         return rc;
     }
@@ -449,6 +475,8 @@ int oval_layout_destroy(oval_ctx* ctx, oval_layout* l)
     if (l->descs_dev) (void)hipFree(l->descs_dev);
     if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
     if (l->chunk_desc_dev) (void)hipFree(l->chunk_desc_dev);
+    if (l->stage_host) (void)hipHostFree(l->stage_host);
+    if (l->built_ev) (void)hipEventDestroy(l->built_ev);
     delete l;
     return OVAL_OK;
 }
@@ -494,6 +522,7 @@ int oval_fill(oval_ctx* ctx, const oval_layout* l, void* body_dev, uint64_t body
     if (l->no_fill)
         return fail(OVAL_E_FIELD, "the layout holds an object whose names do not format to 28 bytes; "
                                   "the reference's Generate fails for it (pattern.go:87-89)");
+    if ((rc = await_tables(ctx, l))) return rc;
     HIP_TRY(oval::launch_fill(ctx->stream, cfg_of(ctx), view_of(l), body_dev, 0, tiles_of(l)));
     return OVAL_OK;
 }
@@ -507,6 +536,7 @@ int oval_validate(oval_ctx* ctx, const oval_layout* l, const void* body_dev, uin
     if (((uintptr_t)results_dev) % 16) return fail(OVAL_E_INVALID, "results_dev is not 16-byte aligned");
     if (((uintptr_t)counters_dev) % 8) return fail(OVAL_E_INVALID, "counters_dev is not 8-byte aligned");
     const oval::LayoutView v = view_of(l);
+    if ((rc = await_tables(ctx, l))) return rc;
     HIP_TRY(oval::launch_init_results(ctx->stream, v, results_dev, (unsigned long long*)counters_dev));
     HIP_TRY(oval::launch_validate(ctx->stream, cfg_of(ctx), v, body_dev, 0, tiles_of(l), results_dev,
                                   (unsigned long long*)counters_dev, ctx->tallies_dev));

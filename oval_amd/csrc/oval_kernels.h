@@ -16,6 +16,7 @@ constexpr uint32_t kUnitsPerChunk = 16;                    // 4 KiB
 constexpr uint32_t kChunksPerTile = 16;
 constexpr uint32_t kUnitsPerTile  = kUnitsPerChunk * kChunksPerTile;   // 64 KiB
 constexpr uint32_t kMaxTilesPerLaunch = 1u << 19;          // 32 GiB of body per kernel launch
+constexpr uint32_t kWarmMinTiles = 64;                    // fills under 4 MiB skip the table pre-pass
 constexpr uint64_t kWarmTableBudget = 32ull << 20;         // lookup-table bytes one fill launch may depend on
 
 // Bad-unit tallies are spread over this many copies of the counter vector, one

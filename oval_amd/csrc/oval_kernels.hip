@@ -523,9 +523,11 @@ hipError_t launch_fill(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv
         const uint32_t t1 = tile_end - t0 > per_launch ? t0 + per_launch : tile_end;
         const uint32_t unit_begin = t0 * kUnitsPerTile;
         const uint32_t n_units = (t1 - t0) * kUnitsPerTile;
-        warm_tables_kernel<<<1024, 256, 0, s>>>(static_cast<const u32x4*>(lv.descs), lv.chunk_first, lv.n_obj,
-                                                t0 * kChunksPerTile, t1 * kChunksPerTile,
-                                                static_cast<const u32x4*>(lv.chunk_desc));
+        // (a launch of a few MiB is over before cold lookups could matter)
+        if (t1 - t0 >= kWarmMinTiles)
+            warm_tables_kernel<<<1024, 256, 0, s>>>(static_cast<const u32x4*>(lv.descs), lv.chunk_first, lv.n_obj,
+                                                    t0 * kChunksPerTile, t1 * kChunksPerTile,
+                                                    static_cast<const u32x4*>(lv.chunk_desc));
 #define OVAL_LAUNCH_FILL(T)                                                                                    \
     do {                                                                                                       \
         if (cd) fill_kernel<T, true><<<n_units / (T / 16), T, 0, s>>>(sd, cf, cd, lv.n_obj, b, unit_begin);     \

@@ -50,7 +50,7 @@ def main():
     stream = torch.cuda.Stream(0)
     torch.cuda.set_stream(stream)
     ctx = engine.Context(0, stream.cuda_stream)
-    layout = timed("layout (upload descriptors, chunk table)", lambda: engine.Layout(ctx, descs))
+    layout = timed("layout (upload descriptors, chunk table)", lambda: (engine.Layout(ctx, descs), ctx.sync())[0])
     body = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
     results = torch.empty((len(descs), 4), dtype=torch.int32, device="cuda:0")
     counters = torch.zeros(engine.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
