@@ -177,7 +177,9 @@ int oval_desc_init(oval_obj_desc* d,
 int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs_host, uint64_t n_obj,
                        oval_layout** out);
 /* Replaces the contents of an existing layout with a new descriptor set,
- * reusing its device memory when it is large enough (no allocation then). */
+ * reusing its device memory when it is large enough (no allocation then).
+ * Waits for the passes issued on this context; no pass that uses the layout
+ * may be in flight on another context. */
 int oval_layout_reset(oval_ctx* ctx, oval_layout* layout, const oval_obj_desc* descs_host,
                       uint64_t n_obj);
 int oval_layout_destroy(oval_ctx* ctx, oval_layout* layout);
