@@ -1,0 +1,45 @@
+"""bench.py's contract on a real GPU: exactly one JSON line on stdout with the
+fields the driver reads, for one rank and for a two-rank rehearsal (gloo, both
+ranks on the one GPU of a test box; the 8-GPU runs use RCCL with one GPU each)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _one_line(cmd):
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_single_rank_line():
+    d = _one_line([sys.executable, "bench.py", "--objects", "40000", "--steps", "3", "--warmup", "1",
+                   "--cpu-seconds", "1"])
+    assert REQUIRED <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "GB/s" and d["dtype"] == "u8" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["value"] > 100 and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
+    assert d["roofline"]["peak"] == 8000.0 and d["roofline"]["launches_per_step"] >= 1
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_two_rank_rehearsal_sums_units_over_ranks():
+    d = _one_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                   "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2",
+                   "--backend", "gloo", "--objects", "40000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"])
+    assert REQUIRED <= set(d) and d["n_gpus"] == 2 and "cpu_baseline" not in d
+    # whole-job value: both ranks' units over the slowest rank's time
+    per_gpu = d["config"]["units_per_gpu"]
+    assert abs(d["value"] - 512.0 * 2 * per_gpu / (d["ms_per_step"] / 1e3) / 1e9) / d["value"] < 0.05
