@@ -36,7 +36,6 @@ struct oval_ctx {
     hipStream_t stream      = nullptr;
     bool        own_stream  = false;
     hipStream_t copy_stream = nullptr;   // second stream for overlapped host copies
-    int         n_cu        = 256;
     int         fill_threads = 256;    // workgroup sizes of the two kernels
     int         validate_threads = 256;
     unsigned long long* tallies_dev = nullptr;   // striped bad-unit tallies of the validate kernels, zero between passes
@@ -183,7 +182,6 @@ int oval_ctx_create(int device_id, void* stream, oval_ctx** out)
     oval_ctx* c = new (std::nothrow) oval_ctx;
     if (!c) return fail(OVAL_E_NOMEM, "out of host memory");
     c->device = device_id;
-    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (stream) {
         c->stream = (hipStream_t)stream;
     } else {
