@@ -66,7 +66,8 @@ struct Job {
     const uint8_t* in = nullptr;   // validate: n_units * 256 bytes of host memory holding the body
     oval_obj_result res{};         // validate: the device's verdict
     bool failed = false;           // the engine failed for the batch this job was in
-    bool done = false;             // micro-batcher: completion flag
+    bool done = false;             // micro-batcher: completion flag ...
+    std::condition_variable* waiter = nullptr;   // ... and who sleeps on it (only that caller is woken)
 };
 
 struct Engine {
@@ -82,6 +83,7 @@ struct Engine {
     size_t res_cap = 0;
     std::vector<oval_obj_desc> descs;
     std::string err;
+    int device = 0;
 
     std::mutex state_mu;           // clock and random source
     int64_t clock = -1;
@@ -90,6 +92,12 @@ struct Engine {
 };
 
 Engine g_engine;
+
+// The micro-batcher runs kBatchLanes launches at a time, each lane a thread
+// with a context (stream, staging) of its own: lane 0 shares g_engine with the
+// direct path, the others own one of these.
+constexpr int kBatchLanes = 2;
+Engine g_lane_engine[kBatchLanes - 1];
 
 uint64_t splitmix64(uint64_t& x)
 {
@@ -133,6 +141,7 @@ int ensure_engine_locked(Engine& e, int device)
     if (e.ctx) return OVAL_OK;
     int rc = oval_ctx_create(device, nullptr, &e.ctx);
     if (rc) return engine_fail(e, rc);
+    e.device = device;
     rc = oval_layout_create(e.ctx, nullptr, 0, &e.layout);
     if (rc) {
         engine_fail(e, rc);
@@ -233,21 +242,22 @@ int run_jobs_locked(Engine& e, Job* const* jobs, size_t n)
 // ---------------------------------------------------------------------------
 struct Batcher {
     std::mutex mu;
-    std::condition_variable work_cv, done_cv;
+    std::condition_variable work_cv;
     std::vector<Job*> queue;
     size_t queued_bytes = 0;
     bool enabled = false, stop = false;
     int window_us = 0;
     size_t max_bytes = 64u << 20;
-    std::thread thread;
+    std::thread threads[kBatchLanes];
     uint64_t batches = 0, jobs = 0;   // statistics
 };
 
 Batcher g_batcher;
 
-void batcher_loop()
+void batcher_loop(int lane)
 {
     Batcher& b = g_batcher;
+    Engine& engine = lane == 0 ? g_engine : g_lane_engine[lane - 1];
     std::unique_lock<std::mutex> lk(b.mu);
     for (;;) {
         b.work_cv.wait(lk, [&] { return b.stop || !b.queue.empty(); });
@@ -266,14 +276,22 @@ void batcher_loop()
         b.queued_bytes = 0;
         lk.unlock();
         {
-            std::lock_guard<std::mutex> ek(g_engine.mu);
-            run_jobs_locked(g_engine, batch.data(), batch.size());
+            std::lock_guard<std::mutex> ek(engine.mu);
+            int rc = ensure_engine_locked(engine, g_engine.device);
+            if (!rc) rc = run_jobs_locked(engine, batch.data(), batch.size());
+            else for (Job* j : batch) j->failed = true;
+            if (rc && &engine != &g_engine) {
+                std::lock_guard<std::mutex> sk(g_engine.state_mu);
+                g_engine.err = engine.err;                      // where callers look for the text
+            }
         }
         lk.lock();
         b.batches++;
         b.jobs += batch.size();
-        for (Job* j : batch) j->done = true;
-        b.done_cv.notify_all();
+        for (Job* j : batch) {
+            j->done = true;
+            j->waiter->notify_one();
+        }
     }
 }
 
@@ -284,10 +302,12 @@ void execute(Job& job)
     {
         std::unique_lock<std::mutex> lk(b.mu);
         if (b.enabled) {
+            std::condition_variable mine;
+            job.waiter = &mine;
             b.queue.push_back(&job);
             b.queued_bytes += (size_t)job.desc.n_units * dataUnitSize;
             b.work_cv.notify_one();
-            b.done_cv.wait(lk, [&] { return job.done; });
+            mine.wait(lk, [&] { return job.done; });
             return;
         }
     }
@@ -417,14 +437,16 @@ void SetMicroBatching(bool enable, int windowMicros, size_t maxBytes)
     if (enable && !b.enabled) {
         b.stop = false;
         b.enabled = true;
-        b.thread = std::thread(batcher_loop);
+        for (int i = 0; i < kBatchLanes; ++i) b.threads[i] = std::thread(batcher_loop, i);
     } else if (!enable && b.enabled) {
         b.enabled = false;       // new callers take the direct path; queued ones are still served
         b.stop = true;
         b.work_cv.notify_all();
-        std::thread t = std::move(b.thread);
+        std::thread ts[kBatchLanes];
+        for (int i = 0; i < kBatchLanes; ++i) ts[i] = std::move(b.threads[i]);
         lk.unlock();
-        if (t.joinable()) t.join();
+        for (std::thread& t : ts)
+            if (t.joinable()) t.join();
     }
 }
 
@@ -435,10 +457,9 @@ void MicroBatchingStats(uint64_t* batches, uint64_t* jobs)
     if (jobs) *jobs = g_batcher.jobs;
 }
 
-void Shutdown()
+namespace {
+void destroy_engine(Engine& e)
 {
-    SetMicroBatching(false, -1, 0);
-    Engine& e = g_engine;
     std::lock_guard<std::mutex> lk(e.mu);
     if (!e.ctx) return;
     oval_ctx_sync(e.ctx);
@@ -450,6 +471,14 @@ void Shutdown()
     oval_ctx_destroy(e.ctx);
     e.ctx = nullptr; e.layout = nullptr; e.dev_body = nullptr; e.pinned = nullptr;
     e.res_dev = nullptr; e.res_host = nullptr; e.dev_cap = 0; e.pinned_cap = 0; e.res_cap = 0;
+}
+}  // namespace
+
+void Shutdown()
+{
+    SetMicroBatching(false, -1, 0);
+    for (Engine& e : g_lane_engine) destroy_engine(e);
+    destroy_engine(g_engine);
 }
 
 void SetClock(int64_t unixMicro)
