@@ -305,15 +305,21 @@ __device__ __forceinline__ uint32_t lane_field_mask(const u32x4& v, uint32_t ex,
                                                     uint32_t force, int j)
 {
     uint32_t fm = 0;
+    // A name field that equals the formatted expected name byte for byte is
+    // accepted without trimming (unless the expected name itself has white
+    // space at an edge, `force`): the usual case for a stale generation, where
+    // only the write count differs.
     if (j == 0) {
         const int blen = (int)(lf & 0xFFu);
-        if (!trimmed_equals([&](int i) { return reg_byte(v, i); }, 16,
-                            [&](int i) { return reg_byte(tmpl, i); }, blen))
+        const bool same = !force && v.x == tmpl.x && v.y == tmpl.y && v.z == tmpl.z && v.w == tmpl.w;
+        if (!same && !trimmed_equals([&](int i) { return reg_byte(v, i); }, 16,
+                                     [&](int i) { return reg_byte(tmpl, i); }, blen))
             fm |= OVAL_BAD_BUCKET;
     } else if (j == 1) {
         const int klen = (int)((lf >> 8) & 0xFFu);
-        if (!trimmed_equals([&](int i) { return reg_byte(v, i); }, 12,
-                            [&](int i) { return reg_byte(tmpl, i); }, klen))
+        const bool same = !force && v.x == tmpl.x && v.y == tmpl.y && v.z == tmpl.z;
+        if (!same && !trimmed_equals([&](int i) { return reg_byte(v, i); }, 12,
+                                     [&](int i) { return reg_byte(tmpl, i); }, klen))
             fm |= OVAL_BAD_KEY;
         if (v.w != tmpl.w) fm |= OVAL_BAD_WRITECNT;
     } else if (j == 2) {

@@ -16,7 +16,12 @@ from oval_amd.batch import WorkerSpace, synthetic_batch, span_bytes
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--objects", type=int, default=1_000_000)
+    ap.add_argument("--lib", default="", help="another build of the library (kernel experiments)")
+    ap.add_argument("--no-check", action="store_true", help="do not compare the counters (timing-only experiments)")
     args = ap.parse_args()
+    if args.lib:
+        from oval_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     stream = torch.cuda.Stream(0)
     torch.cuda.set_stream(stream)
     ctx = engine.Context(0, stream.cuda_stream)
@@ -45,7 +50,8 @@ def main():
             ms.append(t.elapsed_ms())
         c = counters.cpu().numpy()
         bad_units = int(descs["n_units"][stale].sum())
-        assert int(c[3]) == bad_units and int(c[1]) == int(stale.sum()), (c, bad_units, stale.sum())
+        if not args.no_check:
+            assert int(c[3]) == bad_units and int(c[1]) == int(stale.sum()), (c, bad_units, stale.sum())
         best = min(ms[1:])
         print(f"stale objects {frac:7.4f}  bad units {bad_units:9d}  validate {best:8.3f} ms  "
               f"{256.0 * units / best / 1e6:8.1f} GB/s", flush=True)
