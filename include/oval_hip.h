@@ -206,6 +206,26 @@ int oval_fill(oval_ctx* ctx, const oval_layout* layout, void* body_dev, uint64_t
 int oval_validate(oval_ctx* ctx, const oval_layout* layout, const void* body_dev,
                   uint64_t body_bytes, oval_obj_result* results_dev, uint64_t* counters_dev);
 
+/* oval_validate for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart
+ * in the reference.  Same results and counters as oval_layout_create +
+ * oval_validate over the same table, but nothing is allocated or freed: the
+ * descriptor table is the caller's, already in device memory (descs_dev[n_obj],
+ * 64-byte aligned, bodies ascending and non-overlapping as oval_layout_create
+ * requires; not checked here since the host never sees it: a table that breaks
+ * the rule gives meaningless results, but nothing outside body_dev[0,
+ * span_bytes), results_dev[0, n_obj) and counters_dev is touched), and the
+ * chunk table and tallies live in a static device array of 4 MiB + 32 KiB that
+ * each GPU the library runs on holds until the process ends.  span_bytes = end
+ * of the last object's body, at most OVAL_NOALLOC_MAX_SPAN (OVAL_E_RANGE
+ * beyond).  Asynchronous on the context's stream.  Every call on a GPU shares
+ * that GPU's one array: calls that overlap on one GPU (two contexts, two
+ * streams) race; calls in stream order do not. */
+#define OVAL_NOALLOC_MAX_SPAN (4ull << 30)
+int oval_validate_noalloc(oval_ctx* ctx, const oval_obj_desc* descs_dev, uint64_t n_obj,
+                          uint64_t span_bytes, const void* body_dev, uint64_t body_bytes,
+                          oval_obj_result* results_dev, uint64_t* counters_dev);
+
 /* Copies the 256 bytes at body_dev + byte_offset to out256 (host) and waits:
  * the unit the host needs to format the reference's error text
  * (pattern.go:141-175). */

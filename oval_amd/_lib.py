@@ -82,6 +82,7 @@ SIGNATURES = {
     "oval_layout_launches": (_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "oval_fill": (_int, [_vp, _vp, _vp, _u64]),
     "oval_validate": (_int, [_vp, _vp, _vp, _u64, _vp, _vp]),
+    "oval_validate_noalloc": (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _vp, _vp]),
     "oval_read_unit": (_int, [_vp, _vp, _u64, _vp]),
     "oval_fill_batch_host": (_int, [_vp, _vp, _u64, _vp, _u64]),
     "oval_validate_batch_host": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _vp]),

@@ -204,6 +204,15 @@ int oval_ctx_create(int device_id, void* stream, oval_ctx** out)
         delete c;
         return fail(OVAL_E_NOMEM, "hipMalloc(tallies): %s", hipGetErrorString(e));
     }
+    // where this GPU keeps the static scratch of oval_validate_noalloc
+    e = oval::noalloc_scratch_init(device_id);
+    if (e != hipSuccess) {
+        (void)hipFree(c->tallies_dev);
+        (void)hipStreamDestroy(c->copy_stream);
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return fail(OVAL_E_HIP, "hipGetSymbolAddress(scratch) on device %d: %s", device_id, hipGetErrorString(e));
+    }
     *out = c;
     return OVAL_OK;
 }
@@ -538,6 +547,33 @@ int oval_validate(oval_ctx* ctx, const oval_layout* l, const void* body_dev, uin
     HIP_TRY(oval::launch_init_results(ctx->stream, v, results_dev, (unsigned long long*)counters_dev));
     HIP_TRY(oval::launch_validate(ctx->stream, cfg_of(ctx), v, body_dev, 0, tiles_of(l), results_dev,
                                   (unsigned long long*)counters_dev, ctx->tallies_dev));
+    return OVAL_OK;
+}
+
+int oval_validate_noalloc(oval_ctx* ctx, const oval_obj_desc* descs_dev, uint64_t n_obj, uint64_t span_bytes,
+                          const void* body_dev, uint64_t body_bytes, oval_obj_result* results_dev,
+                          uint64_t* counters_dev)
+{
+    if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
+    if (n_obj >= 0xFFFFFFF0ull) return fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
+    if (span_bytes % OVAL_UNIT_SIZE) return fail(OVAL_E_INVALID, "span_bytes %llu is not a multiple of 256",
+                                                 (unsigned long long)span_bytes);
+    if (span_bytes > OVAL_NOALLOC_MAX_SPAN)
+        return fail(OVAL_E_RANGE, "span of %llu bytes is beyond the %llu bytes the static chunk table covers; "
+                                  "use oval_layout_create + oval_validate",
+                    (unsigned long long)span_bytes, (unsigned long long)OVAL_NOALLOC_MAX_SPAN);
+    if (n_obj && (!descs_dev || !results_dev)) return fail(OVAL_E_INVALID, "NULL argument");
+    if (span_bytes && !body_dev) return fail(OVAL_E_INVALID, "body is NULL");
+    if (((uintptr_t)descs_dev) % 64) return fail(OVAL_E_INVALID, "descs_dev is not 64-byte aligned");
+    if (((uintptr_t)body_dev) % 256) return fail(OVAL_E_INVALID, "body pointer %p is not 256-byte aligned", body_dev);
+    if (((uintptr_t)results_dev) % 16) return fail(OVAL_E_INVALID, "results_dev is not 16-byte aligned");
+    if (((uintptr_t)counters_dev) % 8) return fail(OVAL_E_INVALID, "counters_dev is not 8-byte aligned");
+    if (body_bytes < span_bytes)
+        return fail(OVAL_E_RANGE, "body holds %llu bytes but the span is %llu", (unsigned long long)body_bytes,
+                    (unsigned long long)span_bytes);
+    HIP_TRY(oval::launch_validate_noalloc(ctx->stream, ctx->device, cfg_of(ctx), descs_dev, (uint32_t)n_obj,
+                                          (uint32_t)(span_bytes / OVAL_UNIT_SIZE), body_dev, results_dev,
+                                          (unsigned long long*)counters_dev));
     return OVAL_OK;
 }
 

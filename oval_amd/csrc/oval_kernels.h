@@ -19,6 +19,10 @@ constexpr uint32_t kMaxTilesPerLaunch = 1u << 19;          // 32 GiB of body per
 constexpr uint32_t kWarmMinTiles = 64;                    // fills under 4 MiB skip the table pre-pass
 constexpr uint64_t kWarmTableBudget = 32ull << 20;         // lookup-table bytes one fill launch may depend on
 
+// The entry point that allocates nothing keeps its chunk table in a static
+// device array sized for this much body: 65,536 tiles = 4 GiB.
+constexpr uint32_t kNoAllocMaxTiles = 1u << 16;
+
 // Bad-unit tallies are spread over this many copies of the counter vector, one
 // 128-byte line each, and folded into the caller's counters after the pass.
 constexpr uint32_t kTallyStripes = 256;
@@ -54,5 +58,12 @@ hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView
                            const void* body, uint32_t tile_begin, uint32_t tile_end,
                            oval_obj_result* results, unsigned long long* counters,
                            unsigned long long* stripes);
+
+// Looks up, once per GPU and with that GPU current, where the static scratch
+// array of launch_validate_noalloc lives in its memory.
+hipError_t noalloc_scratch_init(int device);
+hipError_t launch_validate_noalloc(hipStream_t s, int device, const LaunchCfg& cfg, const void* descs_dev,
+                                   uint32_t n_obj, uint32_t span_units, const void* body,
+                                   oval_obj_result* results, unsigned long long* counters);
 
 }  // namespace oval

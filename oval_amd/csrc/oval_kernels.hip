@@ -32,6 +32,8 @@
 // Stores are non-temporal: a fill that leaves its lines dirty in L2 / Infinity
 // Cache makes the validate pass that follows pay for their write-back (measured:
 // validate 6.9 -> 5.3 TB/s behind a plain-store fill).
+#include <mutex>
+
 #include "oval_kernels.h"
 #include "oval_trimspace.h"
 
@@ -481,6 +483,54 @@ __global__ __launch_bounds__(256) void init_results_kernel(u32x4* __restrict__ r
     }
 }
 
+// The same for a caller that does not know the sum of n_units: it is taken
+// from the descriptor table here (one atomicAdd per wavefront).
+__global__ __launch_bounds__(256) void init_results_sum_kernel(u32x4* __restrict__ results,
+                                                               const u32x4* __restrict__ descs, uint32_t n_obj,
+                                                               unsigned long long* __restrict__ counters)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    unsigned long long units = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_obj; i += stride) {
+        results[i] = (u32x4){kNone, kNone, 0u, kNone};
+        units += descs[4u * i + 3u].z;
+    }
+    if (!counters) return;
+    for (int d = 32; d > 0; d >>= 1) units += __shfl_xor(units, d);
+    if ((threadIdx.x & 63) == 0 && units) atomicAdd(&counters[OVAL_CNT_UNITS_CHECKED], units);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[OVAL_CNT_OBJECTS_CHECKED], (unsigned long long)n_obj);
+}
+
+// ---------------------------------------------------------------------------
+// Scratch of the entry point that allocates nothing (launch_validate_noalloc):
+// the striped tallies followed by the chunk table of the largest body it
+// accepts.  One copy per GPU the library runs on, held until the process ends.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kScratchTallyWords = (uint32_t)(kTallyBytes / 4);
+constexpr uint32_t kNoAllocMaxChunks = kNoAllocMaxTiles * kChunksPerTile;
+static __device__ __align__(256) uint32_t scratch[kScratchTallyWords + kNoAllocMaxChunks];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};   // device address of `scratch` on each GPU
+}  // namespace
+
+// Called with `device` current.  The array's name is only a handle on the host;
+// its address in a GPU's memory comes from hipGetSymbolAddress, per GPU.
+hipError_t noalloc_scratch_init(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    g_scratch_ptr[device] = p;
+    return hipSuccess;
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -593,6 +643,47 @@ hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView
     if (!counters) return hipSuccess;
     fold_tallies_kernel<<<1, 256, 0, s>>>(stripes, counters);
     return hipGetLastError();
+}
+
+// oval_validate for a caller that cannot allocate: the chunk table and the
+// tallies live in `scratch`, addressed through the pointer kept for `device`.
+// Every call on a GPU uses that GPU's one array: the tallies are cleared and the
+// chunk table rebuilt here, in stream order, and calls that overlap on a GPU race.
+hipError_t launch_validate_noalloc(hipStream_t s, int device, const LaunchCfg& cfg, const void* descs_dev,
+                                   uint32_t n_obj, uint32_t span_units, const void* body,
+                                   oval_obj_result* results, unsigned long long* counters)
+{
+    void* base = nullptr;
+    if (device >= 0 && device < kMaxDevices) {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        base = g_scratch_ptr[device];
+    }
+    if (!base) return hipErrorNotInitialized;
+    unsigned long long* const tallies = static_cast<unsigned long long*>(base);
+    uint32_t* const chunk_first = static_cast<uint32_t*>(base) + kScratchTallyWords;
+    LayoutView lv;
+    lv.descs = descs_dev;
+    lv.chunk_desc = nullptr;
+    lv.chunk_first = chunk_first;
+    lv.n_obj = n_obj;
+    lv.n_tiles = (span_units + kUnitsPerTile - 1u) / kUnitsPerTile;
+    lv.span_units = span_units;
+    lv.total_units = 0;
+    if (lv.n_tiles > kNoAllocMaxTiles) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(tallies, 0, kTallyBytes, s);
+    if (e != hipSuccess) return e;
+    if (n_obj) {
+        e = launch_build_chunk_table(s, descs_dev, n_obj, chunk_first, nullptr, lv.n_tiles);
+        if (e != hipSuccess) return e;
+    }
+    uint32_t blocks = (n_obj + 255u) / 256u;
+    if (blocks > 2048u) blocks = 2048u;
+    if (blocks == 0u) blocks = 1u;
+    init_results_sum_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<u32x4*>(results),
+                                                   static_cast<const u32x4*>(descs_dev), n_obj, counters);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_validate(s, cfg, lv, body, 0, lv.n_tiles, results, counters, tallies);
 }
 
 }  // namespace oval
