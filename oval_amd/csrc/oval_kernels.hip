@@ -248,7 +248,7 @@ struct WRun {
 };
 
 struct WTotals {
-    uint32_t units, bucket, key, wc, off, wid, strict;
+    uint32_t units, bucket, key, wc, off, wid, strict, objs;
 };
 
 // Bad-unit tallies go to one of kTallyStripes copies of the counter vector (one
@@ -261,14 +261,25 @@ __device__ __forceinline__ unsigned long long* tally_of(unsigned long long* stri
     return stripes + (size_t)(blockIdx.x & (kTallyStripes - 1u)) * kTallyStride;
 }
 
-// One lane publishes the wavefront's outcome for object w.o: a 64-bit
-// atomicMin keeps the lowest bad unit together with its field mask.
+// One lane publishes the wavefront's outcome for object w.o.  An object that
+// lies wholly inside this wavefront's chunk [g0, g0 + 16) has no other writer:
+// its result is stored plainly and it is counted as a bad object in the
+// wavefront's own tallies.  Otherwise a 64-bit atomicMin keeps the lowest bad
+// unit together with its field mask.
 __device__ __forceinline__ void w_flush(oval_obj_result* __restrict__ results,
                                         unsigned long long* __restrict__ stripes, const WObj& w, WRun& r,
-                                        int lane)
+                                        WTotals& t, uint32_t g0, int lane)
 {
     if (r.cnt != 0u || r.sfirst != kNone) {
-        if (lane == 0) {
+        const bool sole = w.start >= g0 && w.end <= g0 + kUnitsPerChunk;
+        if (sole) {
+            if (lane == 0) {
+                const uint32_t first = r.cnt != 0u ? r.first + w.ubias : kNone;
+                const uint32_t mask = r.cnt != 0u ? r.mask : kNone;
+                reinterpret_cast<u32x4*>(results)[w.o] = (u32x4){mask, first, r.cnt, r.sfirst + w.ubias};
+            }
+            t.objs += r.cnt != 0u ? 1u : 0u;
+        } else if (lane == 0) {
             oval_obj_result* R = results + w.o;
             if (r.cnt != 0u) {
                 const unsigned long long key =
@@ -290,6 +301,7 @@ __device__ __forceinline__ void w_totals_flush(unsigned long long* __restrict__ 
 {
     if (stripes && tot.strict != 0u && lane == 0) {
         unsigned long long* counters = tally_of(stripes);
+        if (tot.objs) atomicAdd(&counters[OVAL_CNT_OBJECTS_BAD], (unsigned long long)tot.objs);
         if (tot.units) atomicAdd(&counters[OVAL_CNT_UNITS_BAD], (unsigned long long)tot.units);
         if (tot.bucket) atomicAdd(&counters[OVAL_CNT_BAD_BUCKET], (unsigned long long)tot.bucket);
         if (tot.key) atomicAdd(&counters[OVAL_CNT_BAD_KEY], (unsigned long long)tot.key);
@@ -403,6 +415,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     WRaw r;
     WObj w;
     w_fetch(descs, n_obj, o0, r);
+    const WRaw r0 = r;                                         // kept for the second walk of a bad wavefront
     w_activate(r, n_obj, w);
     u32x4 tmpl = w_lane_template(w, j, cpat);
     uint32_t force = w_lane_force(w, j);
@@ -422,12 +435,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
     if (!__any(anybad != 0u)) return;
 
-    w_fetch(descs, n_obj, o0, r);
-    w_activate(r, n_obj, w);
+    w_activate(r0, n_obj, w);
     tmpl = w_lane_template(w, j, cpat);
     force = w_lane_force(w, j);
     WRun run = {kNone, 0, 0, kNone};
-    WTotals tot = {0, 0, 0, 0, 0, 0, 0};
+    WTotals tot = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
         const uint32_t g4 = g0 + 4u * i;
@@ -438,14 +450,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
             const bool bad = (g >= w.start && g < w.end) && ((w_diff(vi, ex, tmpl, zwmask) | force) != 0u);
             if (__any(bad)) w_handle_bad(vi, ex, tmpl, w.lf, force, bad, j, g4, run, tot);
             if (w.end >= g4 + 4u) break;
-            w_flush(results, stripes, w, run, lane);
+            w_flush(results, stripes, w, run, tot, g0, lane);
             w_fetch(descs, n_obj, w.o + 1u, r);
             w_activate(r, n_obj, w);
             tmpl = w_lane_template(w, j, cpat);
             force = w_lane_force(w, j);
         }
     }
-    if (w.o < n_obj) w_flush(results, stripes, w, run, lane);
+    if (w.o < n_obj) w_flush(results, stripes, w, run, tot, g0, lane);
     w_totals_flush(stripes, tot, lane);
 }
 
