@@ -177,9 +177,12 @@ int oval_desc_init(oval_obj_desc* d,
 int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs_host, uint64_t n_obj,
                        oval_layout** out);
 /* Replaces the contents of an existing layout with a new descriptor set,
- * reusing its device memory when it is large enough (no allocation then).
- * Waits for the passes issued on this context; no pass that uses the layout
- * may be in flight on another context. */
+ * reusing its device memory when it is large enough: then nothing is allocated
+ * and the device is not waited for (the new tables are written in stream order
+ * behind the passes already issued on this context).  When it has to grow, it
+ * waits for those passes first.  No pass that uses the layout may be in flight
+ * on another context.  The OVAL_DESC_BUCKET_SLOW / KEY_SLOW bits of the copy
+ * are derived from the names, whatever the caller's flags say. */
 int oval_layout_reset(oval_ctx* ctx, oval_layout* layout, const oval_obj_desc* descs_host,
                       uint64_t n_obj);
 int oval_layout_destroy(oval_ctx* ctx, oval_layout* layout);

@@ -94,6 +94,10 @@ int oval_pattern_valid_batch(size_t n, const int64_t* worker_ids, const char* co
  * Generate / Valid one object at a time, internal/runner/worker.go:64-200):
  * while enabled, calls arriving within window_us share one device launch. */
 void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes);
+/* Batches in flight at once (1..8, default 2) and whether a lane thread sleeps
+ * on an interrupt (1) or polls (0, default) while its batch is on the device.
+ * Values <= 0 / < 0 keep the current setting; applies from the next enable. */
+void oval_pattern_set_lanes(int lanes, int blocking_sync);
 void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs);
 
 /* pattern.dump — pattern.go:182-206; and encoding/hex.Dump which feeds it.

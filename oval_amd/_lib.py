@@ -111,6 +111,7 @@ SIGNATURES = {
     "oval_pattern_valid_stream": (_int, [_i64, _cp, _sz, _cp, _sz, _i64, _i64, _vp, _vp, _cp, _sz]),
     "oval_pattern_set_stream_chunk": (None, [_sz]),
     "oval_pattern_set_batching": (None, [_int, _int, _sz]),
+    "oval_pattern_set_lanes": (None, [_int, _int]),
     "oval_pattern_batching_stats": (None, [C.POINTER(_u64), C.POINTER(_u64)]),
     "oval_pattern_dump": (_sz, [_cp, _sz, _cp, _sz]),
     "oval_pattern_hex_dump": (_sz, [_vp, _sz, _cp, _sz]),

@@ -353,13 +353,36 @@ int oval_desc_init(oval_obj_desc* d, const char* bucket, size_t bucket_len, cons
     return OVAL_OK;
 }
 
-// Checks a descriptor set and computes its totals.
+// true when the name certainly has no white space at either edge: both edge
+// bytes are ASCII and not space (a multi-byte white-space rune starts with a
+// byte >= 0xC2 and ends with one >= 0x80)
+static inline bool edges_plain(const uint8_t* s, size_t n)
+{
+    return n == 0 || (s[0] < 0x80u && !oval::ascii_space(s[0]) && s[n - 1] < 0x80u && !oval::ascii_space(s[n - 1]));
+}
+
+// The OVAL_DESC_*_SLOW bits a descriptor must carry: they follow from the
+// names, so they are derived here rather than trusted (a table assembled without
+// oval_desc_init would otherwise validate "name " clean on the 128-bit path
+// where the reference's TrimSpace compare reports every unit, pattern.go:140,147).
+static inline uint16_t slow_flags_of(const oval_obj_desc& d)
+{
+    uint16_t f = 0;
+    if (!edges_plain(d.bucket, d.bucket_len) && go_space_at_edges(d.bucket, d.bucket_len)) f |= OVAL_DESC_BUCKET_SLOW;
+    if (!edges_plain(d.key, d.key_len) && go_space_at_edges(d.key, d.key_len)) f |= OVAL_DESC_KEY_SLOW;
+    return f;
+}
+
+// Checks a descriptor set and computes its totals.  `fix` receives the indices
+// of the descriptors whose OVAL_DESC_*_SLOW bits differ from what their names
+// demand.
 static int scan_descs(const oval_obj_desc* descs, uint64_t n_obj, uint64_t* total_units_out,
-                      uint64_t* span_bytes_out, bool* no_fill_out)
+                      uint64_t* span_bytes_out, bool* no_fill_out, std::vector<uint64_t>* fix)
 {
     bool no_fill = false;
     if (n_obj >= 0xFFFFFFF0ull) return fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
     uint64_t prev_end = 0, total_units = 0;
+    const uint16_t slow_bits = OVAL_DESC_BUCKET_SLOW | OVAL_DESC_KEY_SLOW;
     for (uint64_t i = 0; i < n_obj; ++i) {
         const oval_obj_desc& d = descs[i];
         if (d.body_offset % OVAL_UNIT_SIZE)
@@ -374,6 +397,7 @@ static int scan_descs(const oval_obj_desc* descs, uint64_t n_obj, uint64_t* tota
         prev_end = d.body_offset + (uint64_t)d.n_units * OVAL_UNIT_SIZE;
         total_units += d.n_units;
         no_fill |= (d.flags & OVAL_DESC_NO_FILL) != 0;
+        if (fix && (d.flags & slow_bits) != slow_flags_of(d)) fix->push_back(i);
         if (prev_end / OVAL_UNIT_SIZE >= 0xFFFFFF00ull)
             return fail(OVAL_E_LAYOUT, "batch spans %llu bytes; the limit is just under 1 TiB",
                         (unsigned long long)prev_end);
@@ -390,13 +414,28 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
     if (l->device != ctx->device) return fail(OVAL_E_INVALID, "layout belongs to device %d, context to %d", l->device, ctx->device);
     uint64_t total_units = 0, span_bytes = 0;
     bool no_fill = false;
-    int rc = scan_descs(descs, n_obj, &total_units, &span_bytes, &no_fill);
+    std::vector<uint64_t> fix;
+    int rc = scan_descs(descs, n_obj, &total_units, &span_bytes, &no_fill, &fix);
     if (rc) return rc;
     const uint64_t span_units = span_bytes / OVAL_UNIT_SIZE;
     const uint32_t n_tiles = (uint32_t)((span_units + oval::kUnitsPerTile - 1) / oval::kUnitsPerTile);
+    const bool one_level = n_obj != 0 && span_bytes / n_obj < (256ull << 10);
     HIP_TRY(hipSetDevice(ctx->device));
-    // a pass that still uses the old tables must finish before they are replaced
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // Until every table is in place the layout describes nothing, so that a
+    // failure below cannot leave counts that point into freed or missing tables.
+    l->n_obj = 0; l->n_tiles = 0; l->total_units = 0; l->span_bytes = 0; l->one_level = false; l->no_fill = false;
+    const bool grow = n_obj > l->cap_obj || !l->descs_dev || n_tiles > l->cap_tiles || !l->chunk_first_dev ||
+                      (one_level && (n_tiles > l->cap_desc_tiles || !l->chunk_desc_dev)) || n_obj > l->cap_stage;
+    if (grow) {
+        // a pass that still uses the old tables must finish before they are freed
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else if (l->built_ev) {
+        // Same capacity: the new tables are written in stream order behind the
+        // passes already issued on this stream, so the device is not waited for;
+        // only the pinned staging copy must have left for the device, which the
+        // previous build's event covers (long complete in the usual case).
+        HIP_TRY(hipEventSynchronize(l->built_ev));
+    }
     if (n_obj > l->cap_obj || !l->descs_dev) {
         if (l->descs_dev) { (void)hipFree(l->descs_dev); l->descs_dev = nullptr; l->cap_obj = 0; }
         const uint64_t cap = n_obj ? n_obj : 1;
@@ -413,22 +452,15 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
     // descriptor per chunk (1.6 % of the body size): the fill then starts with one
     // lookup instead of two dependent ones, worth 6-10 % on 4 KiB ... 64 KiB
     // objects; for larger objects the extra table reads cost more than they save.
-    l->one_level = n_obj != 0 && span_bytes / n_obj < (256ull << 10);
-    if (l->one_level && (n_tiles > l->cap_desc_tiles || !l->chunk_desc_dev)) {
+    if (one_level && (n_tiles > l->cap_desc_tiles || !l->chunk_desc_dev)) {
         if (l->chunk_desc_dev) { (void)hipFree(l->chunk_desc_dev); l->chunk_desc_dev = nullptr; l->cap_desc_tiles = 0; }
         const uint32_t cap = n_tiles ? n_tiles : 1;
         HIP_TRY(hipMalloc(&l->chunk_desc_dev, (size_t)cap * oval::kChunksPerTile * sizeof(oval_obj_desc)));
         l->cap_desc_tiles = cap;
     }
-    l->n_obj = n_obj;
-    l->no_fill = no_fill;
-    l->total_units = total_units;
-    l->span_bytes = span_bytes;
-    l->n_tiles = n_tiles;
     // The caller's array is not retained and may be pageable: it is copied to a
     // pinned buffer of the layout's here, and goes to the device from there in
-    // stream order, so this call does not wait for the device.  (The buffer's
-    // previous contents are out of use: the stream was drained above.)
+    // stream order, so this call does not wait for the device.
     if (n_obj) {
         if (n_obj > l->cap_stage) {
             if (l->stage_host) { (void)hipHostFree(l->stage_host); l->stage_host = nullptr; l->cap_stage = 0; }
@@ -436,14 +468,23 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
             l->cap_stage = n_obj;
         }
         std::memcpy(l->stage_host, descs, n_obj * sizeof(oval_obj_desc));
+        oval_obj_desc* staged = static_cast<oval_obj_desc*>(l->stage_host);
+        const uint16_t slow_bits = OVAL_DESC_BUCKET_SLOW | OVAL_DESC_KEY_SLOW;
+        for (uint64_t i : fix) staged[i].flags = (uint16_t)((staged[i].flags & ~slow_bits) | slow_flags_of(staged[i]));
         HIP_TRY(hipMemcpyAsync(l->descs_dev, l->stage_host, n_obj * sizeof(oval_obj_desc), hipMemcpyHostToDevice,
                                ctx->stream));
     }
     HIP_TRY(oval::launch_build_chunk_table(ctx->stream, l->descs_dev, (uint32_t)n_obj, l->chunk_first_dev,
-                                           l->one_level ? l->chunk_desc_dev : nullptr, n_tiles));
+                                           one_level ? l->chunk_desc_dev : nullptr, n_tiles));
     if (!l->built_ev) HIP_TRY(hipEventCreateWithFlags(&l->built_ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(l->built_ev, ctx->stream));
     l->built_on = ctx->stream;
+    l->one_level = one_level;
+    l->n_obj = n_obj;
+    l->no_fill = no_fill;
+    l->total_units = total_units;
+    l->span_bytes = span_bytes;
+    l->n_tiles = n_tiles;
     return OVAL_OK;
 }
 

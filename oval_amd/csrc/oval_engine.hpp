@@ -1,0 +1,63 @@
+// oval_engine.hpp — the device pipeline behind the host mirror of
+// internal/pattern (oval_pattern.cpp): staging slots, the micro-batcher that
+// folds concurrent single-object calls (one per worker goroutine,
+// internal/runner/runner.go:186-214; internal/runner/worker.go:64-200) into
+// shared launches, and the double-buffered chunk stream behind Valid(reader).
+// Internal to the library.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../include/oval_hip.h"
+
+namespace oval {
+namespace engine {
+
+// One object's worth of device work.
+struct Job {
+    bool is_fill = true;
+    oval_obj_desc desc{};          // body_offset is assigned by the engine
+    uint8_t* out = nullptr;        // fill: n_units * 256 bytes of host memory that receive the body
+    const uint8_t* in = nullptr;   // validate: n_units * 256 bytes of host memory that hold the body
+    oval_obj_result res{};         // validate: the device's verdict
+    bool failed = false;           // the engine (not the data) failed; `err` says how
+    std::string err;
+};
+
+int  init(int device);             // oval_status; idempotent
+void shutdown();
+std::string last_error();          // text of the most recent engine failure
+
+// Runs the jobs as one batch in a staging slot of their own and waits.
+void run(Job* const* jobs, size_t n);
+// One job: through the micro-batcher while it is enabled (and the job is small
+// enough to share a slot), else as a batch of one.
+void execute(Job& job);
+
+void set_batching(bool enable, int window_us, size_t max_bytes);
+// Lanes = batches in flight at once (1..8); blocking = lanes sleep on an
+// interrupt while their batch is on the device instead of polling.  Takes
+// effect when batching is next enabled.
+void set_lanes(int lanes, int blocking);
+void stats(uint64_t* batches, uint64_t* jobs);
+// Where the lane threads' time went since the last reset, summed over lanes:
+// ns waiting for callers still copying in, ns enqueueing, ns waiting for the
+// device, ns publishing + waking, ns re-taking the lock, batches, body bytes.
+constexpr int kProfileWords = 8;
+void lane_profile(uint64_t out[kProfileWords], bool reset);
+
+// Double-buffered validation of one object's body as it arrives: the caller
+// reads chunk k+1 into one pinned half while chunk k is on the device.
+struct Stream;
+Stream* stream_open(size_t chunk_bytes, std::string* err);
+uint8_t* stream_buffer(Stream* st, int half);              // pinned, chunk_bytes long
+// Validates the first desc.n_units units of half `half` against `desc`
+// (asynchronous); stream_wait returns that half's verdict.
+int stream_submit(Stream* st, int half, const oval_obj_desc& desc);
+int stream_wait(Stream* st, int half, oval_obj_result* res);
+std::string stream_error(Stream* st);
+void stream_close(Stream* st);
+
+}  // namespace engine
+}  // namespace oval

@@ -59,6 +59,13 @@ hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView
                            oval_obj_result* results, unsigned long long* counters,
                            unsigned long long* stripes);
 
+// One launch for a small batch whose descriptors, bodies and results all live in
+// pinned host memory: n_val validate jobs (bodies at byte offsets into up_host,
+// one result each into results_host) and n_fill fill jobs (into down_host).
+// Descriptor offsets and lengths are the caller's responsibility: nothing is checked.
+hipError_t launch_host_batch(hipStream_t s, const void* vdescs, uint32_t n_val, const void* fdescs, uint32_t n_fill,
+                             const void* up_host, void* down_host, oval_obj_result* results_host);
+
 // Looks up, once per GPU and with that GPU current, where the static scratch
 // array of launch_validate_noalloc lives in its memory.
 hipError_t noalloc_scratch_init(int device);

@@ -461,6 +461,90 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     w_totals_flush(stripes, tot, lane);
 }
 
+// ---------------------------------------------------------------------------
+// Small batches whose bodies live in pinned host memory (the micro-batched
+// single-object calls of the host mirror: Generate / Valid one 4-16 KiB object
+// per call, internal/runner/worker.go:64-200).  One launch does everything:
+// workgroup b takes job b (validate jobs first, then fill jobs), reads its
+// 64-byte descriptor from host memory, and streams the body over PCIe directly
+// (loads from / non-temporal stores to the pinned buffer), so a batch costs one
+// kernel launch instead of copies + table builds + two launches + copies.  A
+// validate job is owned by one workgroup, so its outcome needs no atomics and
+// no initialisation: the four wavefronts combine in LDS and one thread stores
+// the 16-byte result to host memory.  Descriptor offsets are byte offsets into
+// `up` (validate) or `down` (fill).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void host_batch_kernel(sdesc_ptr vdescs, sdesc_ptr fdescs, uint32_t n_val,
+                                                         const u32x4* __restrict__ up, u32x4* __restrict__ down,
+                                                         u32x4* __restrict__ results)
+{
+    __shared__ uint32_t part[4][4];                            // per wavefront: first, mask, cnt, sfirst
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const uint32_t grp = (uint32_t)lane >> 4;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gmul = (j == 2) ? 256u : 0u;
+    const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
+                        filler_dword(4u * j + 3u)};
+    const bool is_val = blockIdx.x < n_val;
+    const uint32_t job = is_val ? blockIdx.x : blockIdx.x - n_val;
+    sdesc_ptr dp = (is_val ? vdescs : fdescs) + 4u * job;
+    WRaw r;
+    r.o = 0;
+    r.d0 = dp[0]; r.d1 = dp[1]; r.d2 = dp[2]; r.d3 = dp[3];
+    WObj w;
+    w_activate(r, 1u, w);
+    const u32x4 tmpl = w_lane_template(w, j, cpat);
+    if (!is_val) {
+        // wavefront wv writes units start + 4 wv + 16 k ... : 1 KiB per store instruction
+        for (uint32_t g4 = w.start + 4u * wv; g4 < w.end; g4 += 16u) {
+            const uint32_t g = g4 + grp;
+            if (g < w.end) {
+                u32x4 e = tmpl;
+                e.x += g * gmul;
+                __builtin_nontemporal_store(e, down + (size_t)g4 * 16u + (uint32_t)lane);
+            }
+        }
+        return;
+    }
+    const uint32_t zwmask = (j == 2) ? 0u : 0xFFFFFFFFu;       // pattern.go:172 "Skip the unix time area."
+    const uint32_t force = w_lane_force(w, j);
+    WRun run = {kNone, 0, 0, kNone};
+    WTotals tot = {0, 0, 0, 0, 0, 0, 0, 0};
+    // 64 units (16 KiB) per round of the workgroup: four loads per thread in flight
+    for (uint32_t base = w.start; base < w.end; base += 64u) {
+        u32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t g4 = base + 16u * i + 4u * wv;
+            v[i] = (u32x4){0u, 0u, 0u, 0u};
+            if (g4 + grp < w.end) v[i] = __builtin_nontemporal_load(up + (size_t)g4 * 16u + (uint32_t)lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t g4 = base + 16u * i + 4u * wv;
+            const uint32_t g = g4 + grp;
+            const uint32_t ex = tmpl.x + g * gmul;
+            const bool bad = g < w.end && ((w_diff(v[i], ex, tmpl, zwmask) | force) != 0u);
+            if (__any(bad)) w_handle_bad(v[i], ex, tmpl, w.lf, force, bad, j, g4, run, tot);
+        }
+    }
+    if (lane == 0) {
+        part[wv][0] = run.first; part[wv][1] = run.mask; part[wv][2] = run.cnt; part[wv][3] = run.sfirst;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t first = kNone, mask = kNone, cnt = 0, sfirst = kNone;
+        for (int k = 0; k < 4; ++k) {
+            if (part[k][2] != 0u && part[k][0] < first) { first = part[k][0]; mask = part[k][1]; }
+            cnt += part[k][2];
+            if (part[k][3] < sfirst) sfirst = part[k][3];
+        }
+        results[job] = (u32x4){mask, first != kNone ? first + w.ubias : kNone, cnt,
+                               sfirst != kNone ? sfirst + w.ubias : kNone};
+    }
+}
+
 // counters += sum of the stripes; the stripes return to zero for the next pass.
 __global__ __launch_bounds__(256) void fold_tallies_kernel(unsigned long long* __restrict__ stripes,
                                                            unsigned long long* __restrict__ counters)
@@ -654,6 +738,16 @@ hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView
     }
     if (!counters) return hipSuccess;
     fold_tallies_kernel<<<1, 256, 0, s>>>(stripes, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_host_batch(hipStream_t s, const void* vdescs, uint32_t n_val, const void* fdescs, uint32_t n_fill,
+                             const void* up_host, void* down_host, oval_obj_result* results_host)
+{
+    if (n_val + n_fill == 0) return hipSuccess;
+    host_batch_kernel<<<n_val + n_fill, 256, 0, s>>>((sdesc_ptr)vdescs, (sdesc_ptr)fdescs, n_val,
+                                                     static_cast<const u32x4*>(up_host), static_cast<u32x4*>(down_host),
+                                                     reinterpret_cast<u32x4*>(results_host));
     return hipGetLastError();
 }
 

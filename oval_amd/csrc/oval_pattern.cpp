@@ -5,6 +5,7 @@
 #include "oval_pattern.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -16,6 +17,7 @@
 
 #include "../../include/oval_hip.h"
 #include "../../include/oval_pattern.h"
+#include "oval_engine.hpp"
 #include "oval_gostr.h"
 #include "oval_trimspace.h"
 
@@ -52,52 +54,31 @@ Object NewObject(int64_t objID)
 namespace pattern {
 
 // ---------------------------------------------------------------------------
-// engine: one context, one reusable layout, growable staging buffers.  All
-// device work goes through run_jobs_locked(), which takes any number of
-// objects at once: the scalar API hands it one job, GenerateBatch/ValidBatch
-// and the micro-batcher hand it many.
+// Host state of the mirror: the clock Generate stamps units with and the
+// source of DecideSize's rand.Float64().  All device work goes through
+// oval::engine (oval_engine.hpp): the scalar API hands it one job at a time
+// (micro-batched with the calls of other threads while that is enabled),
+// GenerateBatch / ValidBatch hand it many.
 // ---------------------------------------------------------------------------
 namespace {
 
-struct Job {
-    bool is_fill = true;
-    oval_obj_desc desc{};          // body_offset is assigned by the runner
-    uint8_t* out = nullptr;        // fill: n_units * 256 bytes of host memory to receive the body
-    const uint8_t* in = nullptr;   // validate: n_units * 256 bytes of host memory holding the body
-    oval_obj_result res{};         // validate: the device's verdict
-    bool failed = false;           // the engine failed for the batch this job was in
-    bool done = false;             // micro-batcher: completion flag ...
-    std::condition_variable* waiter = nullptr;   // ... and who sleeps on it (only that caller is woken)
-};
+using engine::Job;
 
-struct Engine {
-    std::mutex mu;                 // serialises use of ctx/layout/staging
-    oval_ctx* ctx = nullptr;
-    oval_layout* layout = nullptr;
-    void* dev_body = nullptr;
-    size_t dev_cap = 0;
-    uint8_t* pinned = nullptr;
-    size_t pinned_cap = 0;
-    oval_obj_result* res_dev = nullptr;
-    oval_obj_result* res_host = nullptr;   // pinned
-    size_t res_cap = 0;
-    std::vector<oval_obj_desc> descs;
-    std::string err;
-    int device = 0;
-
-    std::mutex state_mu;           // clock and random source
-    int64_t clock = -1;
-    uint64_t rng[4] = {0, 0, 0, 0};
+// The source of rand.Float64() (pattern.go:63).  Go's global source is one
+// locked generator; with 255 worker threads calling DecideSize that lock is a
+// convoy, so every thread draws from a stream of its own, derived from the seed
+// and the order in which threads first ask: the first thread after Seed(s) gets
+// the stream a single-threaded program has always got.
+struct HostState {
+    std::mutex mu;                      // seed and stream numbering
+    std::atomic<int64_t> clock{-1};
+    uint64_t seed = 0;
     bool seeded = false;
+    std::atomic<uint64_t> epoch{1};     // bumped by Seed(): threads re-derive their stream
+    uint64_t next_stream = 0;
 };
 
-Engine g_engine;
-
-// The micro-batcher runs kBatchLanes launches at a time, each lane a thread
-// with a context (stream, staging) of its own: lane 0 shares g_engine with the
-// direct path, the others own one of these.
-constexpr int kBatchLanes = 2;
-Engine g_lane_engine[kBatchLanes - 1];
+HostState g_state;
 
 uint64_t splitmix64(uint64_t& x)
 {
@@ -107,21 +88,30 @@ uint64_t splitmix64(uint64_t& x)
     return z ^ (z >> 31);
 }
 
-void seed_locked(Engine& e, uint64_t seed)
-{
-    for (auto& w : e.rng) w = splitmix64(seed);
-    e.seeded = true;
-}
+struct ThreadRng {
+    uint64_t s[4] = {0, 0, 0, 0};
+    uint64_t epoch = 0;
+};
 
 // xoshiro256** -> uniform double in [0,1) with 53 random bits, like rand.Float64()
-double float64_locked(Engine& e)
+double next_float64()
 {
-    if (!e.seeded) {
-        std::random_device rd;
-        seed_locked(e, ((uint64_t)rd() << 32) ^ rd());
+    thread_local ThreadRng r;
+    const uint64_t epoch = g_state.epoch.load(std::memory_order_acquire);
+    if (r.epoch != epoch) {
+        std::lock_guard<std::mutex> lk(g_state.mu);
+        if (!g_state.seeded) {
+            std::random_device rd;
+            g_state.seed = ((uint64_t)rd() << 32) ^ rd();
+            g_state.seeded = true;
+        }
+        // stream k starts from the seed advanced by k odd constants: stream 0 is the seed itself
+        uint64_t x = g_state.seed + 0xD1342543DE82EF95ull * g_state.next_stream++;
+        for (auto& w : r.s) w = splitmix64(x);
+        r.epoch = g_state.epoch.load(std::memory_order_relaxed);
     }
     auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
-    uint64_t* s = e.rng;
+    uint64_t* s = r.s;
     const uint64_t result = rotl(s[1] * 5, 7) * 9;
     const uint64_t t = s[1] << 17;
     s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
@@ -130,198 +120,17 @@ double float64_locked(Engine& e)
     return (double)(result >> 11) * 0x1.0p-53;
 }
 
-int engine_fail(Engine& e, int rc)
+Error engine_error(const Job& job)
 {
-    e.err = oval_last_error();
-    return rc;
+    return Error::New("oval engine failure: " + job.err);
 }
 
-int ensure_engine_locked(Engine& e, int device)
-{
-    if (e.ctx) return OVAL_OK;
-    int rc = oval_ctx_create(device, nullptr, &e.ctx);
-    if (rc) return engine_fail(e, rc);
-    e.device = device;
-    rc = oval_layout_create(e.ctx, nullptr, 0, &e.layout);
-    if (rc) {
-        engine_fail(e, rc);
-        oval_ctx_destroy(e.ctx);
-        e.ctx = nullptr;
-        return rc;
-    }
-    return OVAL_OK;
-}
-
-int ensure_buffers_locked(Engine& e, size_t bytes, size_t n_results)
-{
-    if (bytes > e.dev_cap) {
-        if (e.dev_body) { oval_ctx_sync(e.ctx); oval_dev_free(e.ctx, e.dev_body); e.dev_body = nullptr; e.dev_cap = 0; }
-        size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
-        cap = (cap + 65535) & ~(size_t)65535;
-        int rc = oval_dev_alloc(e.ctx, cap, &e.dev_body);
-        if (rc) return engine_fail(e, rc);
-        e.dev_cap = cap;
-    }
-    if (bytes > e.pinned_cap) {
-        if (e.pinned) { oval_ctx_sync(e.ctx); oval_pinned_free(e.ctx, e.pinned); e.pinned = nullptr; e.pinned_cap = 0; }
-        size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes + bytes / 4;
-        int rc = oval_pinned_alloc(e.ctx, cap, (void**)&e.pinned);
-        if (rc) return engine_fail(e, rc);
-        e.pinned_cap = cap;
-    }
-    if (n_results > e.res_cap) {
-        oval_ctx_sync(e.ctx);
-        if (e.res_dev) oval_dev_free(e.ctx, e.res_dev);
-        if (e.res_host) oval_pinned_free(e.ctx, e.res_host);
-        e.res_dev = nullptr; e.res_host = nullptr; e.res_cap = 0;
-        const size_t cap = n_results < 64 ? 64 : n_results * 2;
-        int rc = oval_dev_alloc(e.ctx, cap * sizeof(oval_obj_result), (void**)&e.res_dev);
-        if (!rc) rc = oval_pinned_alloc(e.ctx, cap * sizeof(oval_obj_result), (void**)&e.res_host);
-        if (rc) return engine_fail(e, rc);
-        e.res_cap = cap;
-    }
-    return OVAL_OK;
-}
-
-Error engine_error(const Engine& e)
-{
-    return Error::New("oval engine failure: " + e.err);
-}
-
-// One pass (fill or validate) over the jobs of one kind.
-int run_pass_locked(Engine& e, Job* const* jobs, size_t n, bool fill)
-{
-    e.descs.clear();
-    uint64_t off = 0;
-    for (size_t i = 0; i < n; ++i) {
-        Job* j = jobs[i];
-        j->desc.body_offset = off;
-        off += (uint64_t)j->desc.n_units * dataUnitSize;
-        e.descs.push_back(j->desc);
-    }
-    if (off == 0) return OVAL_OK;
-    int rc = ensure_buffers_locked(e, off, fill ? 0 : n);
-    if (rc) return rc;
-    if ((rc = oval_layout_reset(e.ctx, e.layout, e.descs.data(), n))) return engine_fail(e, rc);
-    if (fill) {
-        if ((rc = oval_fill(e.ctx, e.layout, e.dev_body, e.dev_cap))) return engine_fail(e, rc);
-        if ((rc = oval_copy_d2h(e.ctx, e.pinned, e.dev_body, off))) return engine_fail(e, rc);
-        if ((rc = oval_ctx_sync(e.ctx))) return engine_fail(e, rc);
-        for (size_t i = 0; i < n; ++i)
-            std::memcpy(jobs[i]->out, e.pinned + jobs[i]->desc.body_offset,
-                        (size_t)jobs[i]->desc.n_units * dataUnitSize);
-    } else {
-        for (size_t i = 0; i < n; ++i)
-            std::memcpy(e.pinned + jobs[i]->desc.body_offset, jobs[i]->in,
-                        (size_t)jobs[i]->desc.n_units * dataUnitSize);
-        if ((rc = oval_copy_h2d(e.ctx, e.dev_body, e.pinned, off))) return engine_fail(e, rc);
-        if ((rc = oval_validate(e.ctx, e.layout, e.dev_body, e.dev_cap, e.res_dev, nullptr))) return engine_fail(e, rc);
-        if ((rc = oval_copy_d2h(e.ctx, e.res_host, e.res_dev, n * sizeof(oval_obj_result)))) return engine_fail(e, rc);
-        if ((rc = oval_ctx_sync(e.ctx))) return engine_fail(e, rc);
-        for (size_t i = 0; i < n; ++i) jobs[i]->res = e.res_host[i];
-    }
-    return OVAL_OK;
-}
-
-// Runs a mixed set of jobs: all fills in one launch, all validates in another.
-int run_jobs_locked(Engine& e, Job* const* jobs, size_t n)
-{
-    int rc = ensure_engine_locked(e, 0);
-    std::vector<Job*> fills, vals;
-    for (size_t i = 0; i < n; ++i) (jobs[i]->is_fill ? fills : vals).push_back(jobs[i]);
-    if (!rc && !fills.empty()) rc = run_pass_locked(e, fills.data(), fills.size(), true);
-    if (!rc && !vals.empty()) rc = run_pass_locked(e, vals.data(), vals.size(), false);
-    if (rc)
-        for (size_t i = 0; i < n; ++i) jobs[i]->failed = true;
-    return rc;
-}
-
-// ---------------------------------------------------------------------------
-// micro-batcher: coalesces concurrent single-object calls (one per worker
-// thread, internal/runner/runner.go:186-214) into device batches.
-// ---------------------------------------------------------------------------
-struct Batcher {
-    std::mutex mu;
-    std::condition_variable work_cv;
-    std::vector<Job*> queue;
-    size_t queued_bytes = 0;
-    bool enabled = false, stop = false;
-    int window_us = 0;
-    size_t max_bytes = 64u << 20;
-    std::thread threads[kBatchLanes];
-    uint64_t batches = 0, jobs = 0;   // statistics
-};
-
-Batcher g_batcher;
-
-void batcher_loop(int lane)
-{
-    Batcher& b = g_batcher;
-    Engine& engine = lane == 0 ? g_engine : g_lane_engine[lane - 1];
-    std::unique_lock<std::mutex> lk(b.mu);
-    for (;;) {
-        b.work_cv.wait(lk, [&] { return b.stop || !b.queue.empty(); });
-        if (b.stop && b.queue.empty()) return;
-        // With window 0 a batch is whatever queued up while the previous one was
-        // on the device (no added latency); a window > 0 also holds the door
-        // open that long for callers arriving together.
-        if (b.window_us > 0) {
-            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b.window_us);
-            while (!b.stop && b.queued_bytes < b.max_bytes &&
-                   b.work_cv.wait_until(lk, deadline) != std::cv_status::timeout) {
-            }
-        }
-        std::vector<Job*> batch;
-        batch.swap(b.queue);
-        b.queued_bytes = 0;
-        lk.unlock();
-        {
-            std::lock_guard<std::mutex> ek(engine.mu);
-            int rc = ensure_engine_locked(engine, g_engine.device);
-            if (!rc) rc = run_jobs_locked(engine, batch.data(), batch.size());
-            else for (Job* j : batch) j->failed = true;
-            if (rc && &engine != &g_engine) {
-                std::lock_guard<std::mutex> sk(g_engine.state_mu);
-                g_engine.err = engine.err;                      // where callers look for the text
-            }
-        }
-        lk.lock();
-        b.batches++;
-        b.jobs += batch.size();
-        for (Job* j : batch) {
-            j->done = true;
-            j->waiter->notify_one();
-        }
-    }
-}
-
-// Executes one job, through the batcher when it is enabled.
-void execute(Job& job)
-{
-    Batcher& b = g_batcher;
-    {
-        std::unique_lock<std::mutex> lk(b.mu);
-        if (b.enabled) {
-            std::condition_variable mine;
-            job.waiter = &mine;
-            b.queue.push_back(&job);
-            b.queued_bytes += (size_t)job.desc.n_units * dataUnitSize;
-            b.work_cv.notify_one();
-            mine.wait(lk, [&] { return job.done; });
-            return;
-        }
-    }
-    Job* p = &job;
-    std::lock_guard<std::mutex> ek(g_engine.mu);
-    run_jobs_locked(g_engine, &p, 1);
-}
+using engine::execute;
 
 int64_t now_unix_micro()
 {
-    {
-        std::lock_guard<std::mutex> lk(g_engine.state_mu);
-        if (g_engine.clock >= 0) return g_engine.clock;
-    }
+    const int64_t pinned = g_state.clock.load(std::memory_order_relaxed);
+    if (pinned >= 0) return pinned;
     using namespace std::chrono;
     return duration_cast<microseconds>(system_clock::now().time_since_epoch()).count();
 }
@@ -422,82 +231,46 @@ double go_log2(double x)
 // ---------------------------------------------------------------------------
 // engine control
 // ---------------------------------------------------------------------------
-int Init(int deviceID)
-{
-    std::lock_guard<std::mutex> lk(g_engine.mu);
-    return ensure_engine_locked(g_engine, deviceID);
-}
+int Init(int deviceID) { return engine::init(deviceID); }
 
 void SetMicroBatching(bool enable, int windowMicros, size_t maxBytes)
 {
-    Batcher& b = g_batcher;
-    std::unique_lock<std::mutex> lk(b.mu);
-    if (windowMicros >= 0) b.window_us = windowMicros;
-    if (maxBytes > 0) b.max_bytes = maxBytes;
-    if (enable && !b.enabled) {
-        b.stop = false;
-        b.enabled = true;
-        for (int i = 0; i < kBatchLanes; ++i) b.threads[i] = std::thread(batcher_loop, i);
-    } else if (!enable && b.enabled) {
-        b.enabled = false;       // new callers take the direct path; queued ones are still served
-        b.stop = true;
-        b.work_cv.notify_all();
-        std::thread ts[kBatchLanes];
-        for (int i = 0; i < kBatchLanes; ++i) ts[i] = std::move(b.threads[i]);
-        lk.unlock();
-        for (std::thread& t : ts)
-            if (t.joinable()) t.join();
-    }
+    engine::set_batching(enable, windowMicros, maxBytes);
 }
 
-void MicroBatchingStats(uint64_t* batches, uint64_t* jobs)
-{
-    std::lock_guard<std::mutex> lk(g_batcher.mu);
-    if (batches) *batches = g_batcher.batches;
-    if (jobs) *jobs = g_batcher.jobs;
-}
+void SetBatchLanes(int lanes, int blockingSync) { engine::set_lanes(lanes, blockingSync); }
 
-namespace {
-void destroy_engine(Engine& e)
-{
-    std::lock_guard<std::mutex> lk(e.mu);
-    if (!e.ctx) return;
-    oval_ctx_sync(e.ctx);
-    if (e.dev_body) oval_dev_free(e.ctx, e.dev_body);
-    if (e.pinned) oval_pinned_free(e.ctx, e.pinned);
-    if (e.res_dev) oval_dev_free(e.ctx, e.res_dev);
-    if (e.res_host) oval_pinned_free(e.ctx, e.res_host);
-    if (e.layout) oval_layout_destroy(e.ctx, e.layout);
-    oval_ctx_destroy(e.ctx);
-    e.ctx = nullptr; e.layout = nullptr; e.dev_body = nullptr; e.pinned = nullptr;
-    e.res_dev = nullptr; e.res_host = nullptr; e.dev_cap = 0; e.pinned_cap = 0; e.res_cap = 0;
-}
-}  // namespace
+void MicroBatchingStats(uint64_t* batches, uint64_t* jobs) { engine::stats(batches, jobs); }
 
-void Shutdown()
-{
-    SetMicroBatching(false, -1, 0);
-    for (Engine& e : g_lane_engine) destroy_engine(e);
-    destroy_engine(g_engine);
-}
+void LaneProfile(uint64_t out[8], bool reset) { engine::lane_profile(out, reset); }
 
-void SetClock(int64_t unixMicro)
-{
-    std::lock_guard<std::mutex> lk(g_engine.state_mu);
-    g_engine.clock = unixMicro;
-}
+void Shutdown() { engine::shutdown(); }
+
+void SetClock(int64_t unixMicro) { g_state.clock.store(unixMicro, std::memory_order_relaxed); }
 
 void Seed(uint64_t seed)
 {
-    std::lock_guard<std::mutex> lk(g_engine.state_mu);
-    seed_locked(g_engine, seed);
+    std::lock_guard<std::mutex> lk(g_state.mu);
+    g_state.seed = seed;
+    g_state.seeded = true;
+    g_state.next_stream = 0;
+    g_state.epoch.fetch_add(1, std::memory_order_release);
 }
 
-const std::string& LastEngineError() { return g_engine.err; }
+std::string LastEngineError() { return engine::last_error(); }
 
 // ---------------------------------------------------------------------------
 // io
 // ---------------------------------------------------------------------------
+const uint8_t* BytesReader::Contiguous(size_t want, size_t* got)
+{
+    const size_t left = n_ - pos_;
+    const uint8_t* p = p_ + pos_;
+    *got = want < left ? want : left;
+    pos_ += *got;
+    return p;
+}
+
 size_t BytesReader::Read(uint8_t* p, size_t n)
 {
     const size_t left = n_ - pos_;
@@ -527,12 +300,7 @@ std::pair<int64_t, Error> DecideSizeFrom(int64_t minSize, int64_t maxSize, doubl
 
 std::pair<int64_t, Error> DecideSize(int64_t minSize, int64_t maxSize)
 {
-    double y;
-    {
-        std::lock_guard<std::mutex> lk(g_engine.state_mu);
-        y = float64_locked(g_engine);
-    }
-    return DecideSizeFrom(minSize, maxSize, y);
+    return DecideSizeFrom(minSize, maxSize, next_float64());
 }
 
 // ---------------------------------------------------------------------------
@@ -581,7 +349,7 @@ Error GenerateInto(int64_t dataSize, int64_t workerID, const std::string& bucket
     Error err = prepare_generate(dataSize, workerID, bucketName, obj, out, job);
     if (!err.nil() || job.desc.n_units == 0) return err;
     execute(job);
-    return job.failed ? engine_error(g_engine) : Error::Nil();
+    return job.failed ? engine_error(job) : Error::Nil();
 }
 
 std::pair<std::vector<uint8_t>, Error> Generate(int64_t dataSize, int64_t workerID,
@@ -605,9 +373,9 @@ std::vector<Error> GenerateBatch(const std::vector<GenerateItem>& items)
         if (errs[i].nil() && jobs[i].desc.n_units > 0) run.push_back(&jobs[i]);
     }
     if (!run.empty()) {
-        std::lock_guard<std::mutex> ek(g_engine.mu);
-        if (run_jobs_locked(g_engine, run.data(), run.size()))
-            for (Job* j : run) errs[(size_t)(j - jobs.data())] = engine_error(g_engine);
+        engine::run(run.data(), run.size());
+        for (Job* j : run)
+            if (j->failed) errs[(size_t)(j - jobs.data())] = engine_error(*j);
     }
     return errs;
 }
@@ -639,7 +407,7 @@ std::pair<std::vector<uint8_t>, Error> generateDataUnit(int64_t unitCount, int64
     std::vector<uint8_t> unit(dataUnitSize);
     job.out = unit.data();
     execute(job);
-    if (job.failed) return {{}, engine_error(g_engine)};
+    if (job.failed) return {{}, engine_error(job)};
     return {std::move(unit), Error::Nil()};
 }
 
@@ -677,7 +445,7 @@ Error validDataUnit(int64_t unitCount, int64_t workerID, const std::string& expe
     const uint32_t forced = validation_desc(expectedBucketName, obj, workerID, (uint32_t)unitCount, 1, &job.desc, &ok);
     if (!ok) return Error::New(std::string("oval engine failure: ") + oval_last_error());
     execute(job);
-    if (job.failed) return engine_error(g_engine);
+    if (job.failed) return engine_error(job);
     uint32_t mask = (job.res.first_bad_unit == OVAL_NO_BAD_UNIT) ? 0u : job.res.first_bad_fields;
     mask |= forced;
     if (mask == 0) return Error::Nil();
@@ -724,7 +492,7 @@ Error finish_valid(int64_t workerID, const object::Object* obj, const uint8_t* b
 {
     if (st.nUnits <= 0) return Error::Nil();
     if (st.has_job) {
-        if (job.failed) return engine_error(g_engine);
+        if (job.failed) return engine_error(job);
         if (st.forced) {
             // a name longer than its field fails in the very first unit; the
             // device still says which of unit 0's other fields are wrong
@@ -764,34 +532,114 @@ Error ValidBytes(int64_t workerID, const std::string& expectedBucketName, const 
 
 namespace {
 
-// Validates units [firstUnit, firstUnit + n) of an object, held in `data`;
-// returns the reference's error for the first bad one, or nil.
-Error validate_span(int64_t workerID, const std::string& bucket16, const object::Object* obj,
-                    uint32_t firstUnit, const uint8_t* data, uint32_t n)
+std::atomic<size_t> g_stream_chunk_bytes{32u << 20};
+
+Error short_read_error(const uint8_t* partial, size_t n)
 {
-    Job job;
-    job.is_fill = false;
-    job.in = data;
-    bool ok = false;
-    const uint32_t forced = validation_desc(bucket16, obj, workerID, firstUnit, n, &job.desc, &ok);
-    if (!ok) return Error::New(std::string("oval engine failure: ") + oval_last_error());
-    execute(job);
-    if (job.failed) return engine_error(g_engine);
+    // pattern.go:125-127 the unit that could not be read in full
+    char head[96];
+    std::snprintf(head, sizeof head, "could not read some data. (expected: %dbyte, actual: %zubyte)\n",
+                  dataUnitSize, n);
+    return Error::New(std::string(head) + dump(hexDump(partial, n)));
+}
+
+// The reference's error for the outcome of units [firstUnit, firstUnit + n) held in `data`, or nil.
+Error span_verdict(const oval_obj_result& res, uint32_t forced, int64_t workerID, const std::string& bucket16,
+                   const object::Object* obj, uint32_t firstUnit, const uint8_t* data)
+{
     if (forced) {
         // a name longer than its field fails in the span's very first unit
         uint32_t mask = forced;
-        if (job.res.first_bad_unit == firstUnit) mask |= job.res.first_bad_fields;
+        if (res.first_bad_unit == firstUnit) mask |= res.first_bad_fields;
         return Error::New(unit_error_text(mask, firstUnit, workerID, bucket16, obj, data));
     }
-    if (job.res.first_bad_unit != OVAL_NO_BAD_UNIT) {
-        const uint8_t* unit = data + (size_t)(job.res.first_bad_unit - firstUnit) * dataUnitSize;
-        return Error::New(unit_error_text(job.res.first_bad_fields, job.res.first_bad_unit, workerID, bucket16,
-                                          obj, unit));
+    if (res.first_bad_unit != OVAL_NO_BAD_UNIT) {
+        const uint8_t* unit = data + (size_t)(res.first_bad_unit - firstUnit) * dataUnitSize;
+        return Error::New(unit_error_text(res.first_bad_fields, res.first_bad_unit, workerID, bucket16, obj, unit));
     }
     return Error::Nil();
 }
 
-size_t g_stream_chunk_bytes = 32u << 20;
+// io.ReadFull unit by unit (pattern.go:124) == read until `want` bytes or EOF
+size_t read_full(Reader& reader, uint8_t* p, size_t want)
+{
+    size_t got = 0;
+    while (got < want) {
+        const size_t n = reader.Read(p + got, want - got);
+        if (n == 0) break;
+        got += n;
+    }
+    return got;
+}
+
+// A body larger than one chunk: chunk k+1 is read straight into one half of a
+// pinned buffer while chunk k, in the other half, is copied to the device and
+// validated.  A chunk's verdict is collected after the next chunk has been
+// read, so the reader may be asked for one chunk more than the reference would
+// have consumed; which error is returned is not affected: the lowest bad unit
+// wins, and a bad unit wins over a short read (pattern.go:124-131).
+Error valid_streaming(int64_t workerID, const std::string& bucket16, const object::Object* obj, Reader& reader,
+                      int64_t nUnits, size_t chunk_bytes)
+{
+    std::string eng_err;
+    engine::Stream* st = engine::stream_open(chunk_bytes, &eng_err);
+    if (!st) return Error::New("oval engine failure: " + eng_err);
+    struct Pending { bool active = false; uint32_t first = 0, forced = 0; };
+    Pending pend[2];
+    Error result = Error::Nil();
+    bool done = false;
+    // collects the verdict of the chunk in `half`; true when it ends the validation
+    auto collect = [&](int half) {
+        Pending& p = pend[half];
+        if (!p.active) return false;
+        p.active = false;
+        oval_obj_result res;
+        if (engine::stream_wait(st, half, &res)) {
+            result = Error::New("oval engine failure: " + engine::stream_error(st));
+            return true;
+        }
+        result = span_verdict(res, p.forced, workerID, bucket16, obj, p.first, engine::stream_buffer(st, half));
+        return !result.nil();
+    };
+    const size_t chunk_units = chunk_bytes / dataUnitSize;
+    int64_t first = 0;
+    for (int k = 0; first < nUnits && !done; ++k) {
+        const int half = k & 1;
+        const size_t want = (size_t)std::min<int64_t>(nUnits - first, (int64_t)chunk_units) * dataUnitSize;
+        uint8_t* buf = engine::stream_buffer(st, half);     // its previous chunk (k-2) was collected in round k-1
+        const size_t got = read_full(reader, buf, want);
+        const size_t complete = got / dataUnitSize;
+        if (complete > 0) {
+            oval_obj_desc d;
+            bool ok = false;
+            pend[half].forced = validation_desc(bucket16, obj, workerID, (uint32_t)first, (uint32_t)complete, &d, &ok);
+            pend[half].first = (uint32_t)first;
+            if (!ok) {
+                result = Error::New(std::string("oval engine failure: ") + oval_last_error());
+                break;
+            }
+            if (engine::stream_submit(st, half, d)) {
+                result = Error::New("oval engine failure: " + engine::stream_error(st));
+                break;
+            }
+            pend[half].active = true;
+        }
+        if (collect(half ^ 1)) break;                        // the chunk before this one
+        if (got < want) {
+            if (collect(half)) break;                        // a bad unit wins over the short read
+            result = short_read_error(buf + complete * dataUnitSize, got - complete * dataUnitSize);
+            done = true;
+        }
+        first += (int64_t)complete;
+    }
+    if (result.nil() && !done) {
+        // the last one or two chunks are still on the device; the earlier one first
+        const int last = pend[0].active && pend[1].active ? (pend[0].first < pend[1].first ? 0 : 1) : (pend[0].active ? 0 : 1);
+        if (!collect(last)) collect(last ^ 1);
+    }
+    engine::stream_close(st);
+    return result;
+}
 
 }  // namespace
 
@@ -801,10 +649,11 @@ void SetStreamChunkBytes(size_t bytes)
     g_stream_chunk_bytes = bytes - bytes % dataUnitSize;
 }
 
-// The body is consumed in chunks of at most SetStreamChunkBytes() (32 MiB by
-// default) so that a multipart-sized object needs neither a body-sized host
-// buffer nor a body-sized device buffer.  Reading stops at the first chunk
-// that holds a bad unit, as the reference stops at the first bad unit.
+// A body of up to one chunk (SetStreamChunkBytes(), 32 MiB by default) is read
+// whole and validated as one job, which the micro-batcher may fold into the
+// same launch as other callers' jobs.  A larger body streams through a pinned
+// double buffer so that neither a body-sized host buffer nor a body-sized
+// device buffer is needed and the reads overlap the device work.
 Error Valid(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
             Reader& reader)
 {
@@ -812,34 +661,19 @@ Error Valid(int64_t workerID, const std::string& expectedBucketName, const objec
     const int64_t nUnits = obj->Size / dataUnitSize;
     if (nUnits <= 0) return Error::Nil();                    // the loop at :123 does not run
     if (nUnits > 0xFFFFFFF0ll) return Error::New("object size beyond the engine's 1 TiB limit");
-    const size_t chunk_units = g_stream_chunk_bytes / dataUnitSize;
-    std::vector<uint8_t> buf((size_t)std::min<int64_t>(nUnits, (int64_t)chunk_units) * dataUnitSize);
-    int64_t done = 0;
-    while (done < nUnits) {
-        const size_t want = (size_t)std::min<int64_t>(nUnits - done, (int64_t)chunk_units) * dataUnitSize;
-        // io.ReadFull unit by unit (:124) == read until `want` bytes or EOF
-        size_t got = 0;
-        while (got < want) {
-            const size_t n = reader.Read(buf.data() + got, want - got);
-            if (n == 0) break;
-            got += n;
-        }
-        const size_t complete = got / dataUnitSize;
-        if (complete > 0) {
-            Error err = validate_span(workerID, bucket16, obj, (uint32_t)done, buf.data(), (uint32_t)complete);
-            if (!err.nil()) return err;                      // :128-131 a bad unit wins over a later short read
-        }
-        if (got < want) {
-            // :125-127 the unit that could not be read in full
-            const size_t n = got - complete * dataUnitSize;
-            char head[96];
-            std::snprintf(head, sizeof head, "could not read some data. (expected: %dbyte, actual: %zubyte)\n",
-                          dataUnitSize, n);
-            return Error::New(std::string(head) + dump(hexDump(buf.data() + complete * dataUnitSize, n)));
-        }
-        done += (int64_t)complete;
+    const size_t chunk_bytes = g_stream_chunk_bytes.load();
+    if ((uint64_t)nUnits * dataUnitSize > chunk_bytes)
+        return valid_streaming(workerID, bucket16, obj, reader, nUnits, chunk_bytes);
+    const size_t want = (size_t)nUnits * dataUnitSize;
+    size_t got = 0;
+    const uint8_t* body = reader.Contiguous(want, &got);     // a reader over memory lends its bytes
+    if (!body) {
+        thread_local std::vector<uint8_t> bounce;
+        if (bounce.size() < want) bounce.resize(want);
+        got = read_full(reader, bounce.data(), want);
+        body = bounce.data();
     }
-    return Error::Nil();
+    return ValidBytes(workerID, expectedBucketName, obj, body, got);
 }
 
 std::vector<Error> ValidBatch(const std::vector<ValidItem>& items)
@@ -853,10 +687,7 @@ std::vector<Error> ValidBatch(const std::vector<ValidItem>& items)
         errs[i] = prepare_valid(it.workerID, it.expectedBucketName, it.obj, it.body, it.bodyLen, sts[i], jobs[i]);
         if (errs[i].nil() && sts[i].has_job) run.push_back(&jobs[i]);
     }
-    if (!run.empty()) {
-        std::lock_guard<std::mutex> ek(g_engine.mu);
-        run_jobs_locked(g_engine, run.data(), run.size());
-    }
+    if (!run.empty()) engine::run(run.data(), run.size());
     for (size_t i = 0; i < items.size(); ++i)
         if (errs[i].nil())
             errs[i] = finish_valid(items[i].workerID, items[i].obj, items[i].body, sts[i], jobs[i]);
@@ -1059,6 +890,8 @@ void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes)
 {
     oval::pattern::SetMicroBatching(enable != 0, window_us, max_bytes);
 }
+
+void oval_pattern_set_lanes(int lanes, int blocking_sync) { oval::pattern::SetBatchLanes(lanes, blocking_sync); }
 
 void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs)
 {

@@ -54,6 +54,9 @@ class Reader {
 public:
     virtual ~Reader() = default;
     virtual size_t Read(uint8_t* p, size_t n) = 0;
+    // A reader over memory may lend its next min(want, remaining) bytes instead
+    // of copying them (and advances past them); NULL = not supported, use Read.
+    virtual const uint8_t* Contiguous(size_t want, size_t* got) { (void)want; (void)got; return nullptr; }
 };
 
 // bytes.NewReader
@@ -61,6 +64,7 @@ class BytesReader : public Reader {
 public:
     BytesReader(const uint8_t* data, size_t len) : p_(data), n_(len) {}
     size_t Read(uint8_t* p, size_t n) override;
+    const uint8_t* Contiguous(size_t want, size_t* got) override;
 private:
     const uint8_t* p_;
     size_t n_;
@@ -125,7 +129,7 @@ int  Init(int deviceID);            // oval_status
 void Shutdown();
 void SetClock(int64_t unixMicro);   // >= 0 pins time.Now().UnixMicro(); < 0 = wall clock
 void Seed(uint64_t seed);           // source of rand.Float64() in DecideSize
-const std::string& LastEngineError();
+std::string LastEngineError();
 // Micro-batching: while enabled, concurrent Generate / Valid calls (one per
 // worker thread, internal/runner/runner.go:186-214) that arrive within
 // `windowMicros` of each other share one device launch; with window 0 a batch is
@@ -133,6 +137,15 @@ const std::string& LastEngineError();
 // identical either way.  A negative window keeps the current setting.
 void SetMicroBatching(bool enable, int windowMicros = 0, size_t maxBytes = 64u << 20);
 void MicroBatchingStats(uint64_t* batches, uint64_t* jobs);
+// Batches in flight at once (1..8) and whether a lane sleeps on an interrupt
+// (1) or polls (0) while its batch is on the device; negative / zero lanes keep
+// the current value.  Applies from the next SetMicroBatching(true).
+void SetBatchLanes(int lanes, int blockingSync);
+// Time the lane threads spent per phase since the last reset, summed over
+// lanes: [0] ns waiting for callers still copying their bodies in, [1] ns
+// enqueueing the batch, [2] ns waiting for the device, [3] ns publishing and
+// waking, [4] ns re-taking the pipeline lock, [5] batches, [6] body bytes.
+void LaneProfile(uint64_t out[8], bool reset);
 // Valid(reader) consumes the body in chunks of at most this many bytes.
 void SetStreamChunkBytes(size_t bytes);
 

@@ -143,6 +143,11 @@ def set_batching(enable: bool, window_us: int = 0, max_bytes: int = 64 << 20) ->
     _lib.lib().oval_pattern_set_batching(1 if enable else 0, window_us, max_bytes)
 
 
+def set_lanes(lanes: int = 0, blocking_sync: int = -1) -> None:
+    """Batches in flight at once / lane threads sleep instead of polling."""
+    _lib.lib().oval_pattern_set_lanes(lanes, blocking_sync)
+
+
 def batching_stats():
     b, j = C.c_uint64(), C.c_uint64()
     _lib.lib().oval_pattern_batching_stats(C.byref(b), C.byref(j))

@@ -1,0 +1,96 @@
+"""The Go binding (go/internal/pattern/pattern_hip.go) cannot be compiled here
+(no Go toolchain), so its contract with the C ABI is checked textually: every
+C.oval_* function it calls is declared in include/*.h with the same number of
+arguments, it defines every symbol the reference's pattern_test.go uses, and it
+carries no placeholder."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GO_FILE = os.path.join(ROOT, "go", "internal", "pattern", "pattern_hip.go")
+
+
+def _strip_c_comments(text):
+    return re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+
+
+def _split_top_level(args):
+    out, depth, cur = [], 0, ""
+    for ch in args:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def _declared_functions():
+    """name -> number of parameters, from every header in include/."""
+    decls = {}
+    inc = os.path.join(ROOT, "include")
+    for fn in sorted(os.listdir(inc)):
+        if not fn.endswith(".h"):
+            continue
+        text = _strip_c_comments(open(os.path.join(inc, fn)).read())
+        for m in re.finditer(r"\b(oval_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+            name, args = m.group(1), m.group(2).strip()
+            n = 0 if args in ("", "void") else len(_split_top_level(args))
+            decls[name] = n
+    return decls
+
+
+def _go_calls(src):
+    """(name, number of arguments) of every C.oval_*( ... ) call."""
+    calls = []
+    for m in re.finditer(r"\bC\.(oval_[a-z0-9_]+)\(", src):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        args = src[m.end():i - 1].strip()
+        calls.append((m.group(1), 0 if not args else len(_split_top_level(args))))
+    return calls
+
+
+def test_every_c_call_matches_a_declaration():
+    src = open(GO_FILE).read()
+    go_code = re.sub(r"//[^\n]*", "", src.split('import "C"', 1)[1])
+    decls = _declared_functions()
+    calls = _go_calls(go_code)
+    assert len(calls) >= 9
+    types = {"oval_read_fn"}                                   # a conversion, not a call
+    for name, n_args in calls:
+        if name in types:
+            continue
+        assert name in decls, f"{name} is called from Go but not declared in include/*.h"
+        assert decls[name] == n_args, f"{name}: Go passes {n_args} arguments, the header declares {decls[name]}"
+    used = {n for n, _ in calls}
+    for must in ("oval_pattern_generate", "oval_pattern_valid_stream", "oval_pattern_decide_size",
+                 "oval_pattern_generate_data_unit", "oval_pattern_valid_data_unit", "oval_pattern_set_batching"):
+        assert must in used, f"the Go binding does not call {must}"
+
+
+def test_go_file_defines_the_reference_surface_and_has_no_placeholders():
+    src = open(GO_FILE).read()
+    assert src.startswith("//go:build ovalhip\n")
+    # internal/pattern/pattern.go:22,73,94,118,136 and the constant pattern_test.go:40,90 read
+    for sig in (r"func DecideSize\(minSize, maxSize int\) \(int, error\)",
+                r"func Generate\(dataSize, workerID int, bucketName string, obj \*object\.Object\) \(\[\]byte, error\)",
+                r"func generateDataUnit\(unitCount, workerID int, bucketName string, obj \*object\.Object\) \(\[\]byte, error\)",
+                r"func Valid\(workerID int, expectedBucketName string, obj \*object\.Object, reader io\.Reader\) error",
+                r"func validDataUnit\(unitCount, workerID int, expectedBucketName string, obj \*object\.Object, data \[\]byte\) error",
+                r"dataUnitSize\s+= 256"):
+        assert re.search(sig, src), sig
+    assert "//export ovalGoRead" in src and "size_t ovalGoRead(void* user, uint8_t* p, size_t n);" in src
+    body = src.split('import "C"', 1)[1]
+    assert "/*" not in body and "TODO" not in src and "..." not in body
+    # the read callback has the type the header gives oval_read_fn
+    hdr = _strip_c_comments(open(os.path.join(ROOT, "include", "oval_pattern.h")).read())
+    assert re.search(r"typedef\s+size_t\s*\(\*oval_read_fn\)\(void\*\s*user,\s*uint8_t\*\s*p,\s*size_t\s+n\)", hdr)

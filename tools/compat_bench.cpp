@@ -4,10 +4,16 @@
 // through the C++ host mirror, with and without micro-batching.
 //
 //   hipcc -O2 -std=c++17 -o build/compat_bench tools/compat_bench.cpp -Ioval_amd/csrc -Loval_amd -loval_hip -Wl,-rpath,$PWD/oval_amd -lpthread
+//
+//   compat_bench [seconds] [threads,threads,...] [lanes,lanes,...] [blocking 0|1|2 (2 = both)] [skip the unbatched run 0|1]
+#include <sys/resource.h>
+
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -15,9 +21,16 @@
 
 using namespace oval;
 
-static void run(int n_threads, double seconds, bool batching, int window_us)
+static void run(int n_threads, double seconds, bool batching, int lanes, int blocking)
 {
-    pattern::SetMicroBatching(batching, window_us);
+    pattern::SetBatchLanes(lanes, blocking);
+    pattern::SetMicroBatching(batching, 0);
+    uint64_t b0 = 0, j0 = 0;
+    pattern::MicroBatchingStats(&b0, &j0);
+    uint64_t prof[8];
+    pattern::LaneProfile(prof, true);
+    rusage ru0;
+    getrusage(RUSAGE_SELF, &ru0);
     std::atomic<bool> stop{false};
     std::atomic<uint64_t> ops{0}, bytes{0}, errors{0};
     std::vector<std::thread> ths;
@@ -25,7 +38,7 @@ static void run(int n_threads, double seconds, bool batching, int window_us)
         ths.emplace_back([&, t] {
             std::vector<object::Object> objs;
             for (int j = 0; j < 256; ++j) objs.push_back(object::NewObject(((int64_t)t << 24) + j));
-            uint64_t i = 0;
+            uint64_t i = 0, my_ops = 0, my_bytes = 0;
             while (!stop.load(std::memory_order_relaxed)) {
                 object::Object& o = objs[i++ % objs.size()];
                 auto sz = pattern::DecideSize(4096, 16384);
@@ -36,9 +49,11 @@ static void run(int n_threads, double seconds, bool batching, int window_us)
                 pattern::BytesReader rd(body.first.data(), body.first.size());
                 Error e = pattern::Valid(0x561B + t, "test-bucket", &o, rd);
                 if (!e.nil()) errors++;
-                ops++;
-                bytes += 2 * (uint64_t)o.Size;
+                my_ops++;
+                my_bytes += 2 * (uint64_t)o.Size;
             }
+            ops += my_ops;
+            bytes += my_bytes;
         });
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -48,22 +63,54 @@ static void run(int n_threads, double seconds, bool batching, int window_us)
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     uint64_t b = 0, j = 0;
     pattern::MicroBatchingStats(&b, &j);
-    std::printf("threads %3d  batching %-3s window %4d us : %9.0f put-cycles/s  %8.3f GB/s generate+validate  errors %llu  (jobs/launch so far %.1f)\n",
-                n_threads, batching ? "on" : "off", window_us, ops / dt, bytes / dt / 1e9,
-                (unsigned long long)errors.load(), b ? (double)j / b : 0.0);
+    std::printf("threads %3d  batching %-3s lanes %d %-8s: %9.0f put-cycles/s  %8.3f GB/s generate+validate  errors %llu  jobs/launch %.1f\n",
+                n_threads, batching ? "on" : "off", lanes, blocking ? "blocking" : "polling", ops / dt, bytes / dt / 1e9,
+                (unsigned long long)errors.load(), b > b0 ? (double)(j - j0) / (double)(b - b0) : 0.0);
+    rusage ru1;
+    getrusage(RUSAGE_SELF, &ru1);
+    auto secs_of = [](const timeval& a, const timeval& b) { return (b.tv_sec - a.tv_sec) + 1e-6 * (b.tv_usec - a.tv_usec); };
+    const double user = secs_of(ru0.ru_utime, ru1.ru_utime), sys = secs_of(ru0.ru_stime, ru1.ru_stime);
+    std::printf("      host CPU: %.1f cores user + %.1f cores system; per put-cycle %.1f us user + %.1f us system; context switches/put-cycle %.1f voluntary + %.2f involuntary\n",
+                user / dt, sys / dt, ops ? user / ops * 1e6 : 0.0, ops ? sys / ops * 1e6 : 0.0,
+                ops ? (double)(ru1.ru_nvcsw - ru0.ru_nvcsw) / ops : 0.0, ops ? (double)(ru1.ru_nivcsw - ru0.ru_nivcsw) / ops : 0.0);
+    pattern::LaneProfile(prof, true);
+    if (batching && prof[5])
+        std::printf("      per batch, us: callers copying in %.1f | enqueue %.1f | device %.1f | publish+wake %.1f | lock %.1f ; %.0f KB/batch, lanes busy %.0f %%\n",
+                    prof[0] / 1e3 / prof[5], prof[1] / 1e3 / prof[5], prof[2] / 1e3 / prof[5], prof[3] / 1e3 / prof[5],
+                    prof[4] / 1e3 / prof[5], prof[6] / 1e3 / prof[5],
+                    100.0 * (prof[0] + prof[1] + prof[2] + prof[3] + prof[4]) / 1e9 / dt / lanes);
+    std::fflush(stdout);
     pattern::SetMicroBatching(false, -1);
+}
+
+static std::vector<int> ints(const char* s)
+{
+    std::vector<int> v;
+    for (const char* p = s; *p;) {
+        v.push_back(atoi(p));
+        p = strchr(p, ',');
+        if (!p) break;
+        ++p;
+    }
+    return v;
 }
 
 int main(int argc, char** argv)
 {
     const double secs = argc > 1 ? atof(argv[1]) : 2.0;
+    const std::vector<int> threads = ints(argc > 2 ? argv[2] : "1,4,16,64,255");
+    const std::vector<int> lanes = ints(argc > 3 ? argv[3] : "4");
+    const int blocking = argc > 4 ? atoi(argv[4]) : 0;
+    const bool skip_off = argc > 5 && atoi(argv[5]) != 0;
     if (pattern::Init(0) != 0) { std::fprintf(stderr, "init failed: %s\n", pattern::LastEngineError().c_str()); return 1; }
     pattern::Seed(1);
-    for (int n : {1, 4, 16, 64, 255}) {
-        run(n, secs, false, 0);
-        run(n, secs, true, 0);
-        run(n, secs, true, 20);
-        run(n, secs, true, 50);
+    std::printf("host threads available to this process: %u\n", std::thread::hardware_concurrency());
+    for (int n : threads) {
+        if (!skip_off) run(n, secs, false, 1, 0);
+        for (int l : lanes) {
+            if (blocking != 1) run(n, secs, true, l, 0);
+            if (blocking != 0) run(n, secs, true, l, 1);
+        }
     }
     pattern::Shutdown();
     return 0;
