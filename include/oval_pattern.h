@@ -70,6 +70,33 @@ int oval_pattern_valid_stream(int64_t worker_id, const char* bucket, size_t buck
                               oval_read_fn read, void* user, char* err, size_t err_cap);
 void oval_pattern_set_stream_chunk(size_t bytes);
 
+/* pattern.Generate for a body that is uploaded in parts.  The reference's
+ * multipartUpload (internal/s3client/s3client.go:164-236) re-slices the []byte
+ * that Generate returned (body[:partSize] at :185, body = body[partSize:] at
+ * :204).  Here the body is generated ONCE into pinned host memory owned by the
+ * library (no copy into caller memory) and part views of part_size bytes are
+ * handed out of it; the body arrives there slice by slice, so part 0 can be on
+ * the wire while later parts are still being copied from the device.
+ * oval_parts_get waits until part `index` (bytes [index * part_size, min((index
+ * + 1) * part_size, data_size))) has landed and returns a pointer into the
+ * buffer, valid until that part is released.  When every part has been released
+ * the buffer returns to the library's pool of pinned allocations;
+ * oval_parts_close releases whatever is still held (the abort path,
+ * s3client.go:190-203) and frees the handle, and must be called exactly once.
+ * Return values as for oval_pattern_generate. */
+typedef struct oval_parts oval_parts;
+int oval_pattern_generate_parts(int64_t data_size, int64_t worker_id,
+                                const char* bucket, size_t bucket_len,
+                                const char* key, size_t key_len, int64_t write_count,
+                                int64_t part_size, oval_parts** out, char* err, size_t err_cap);
+int64_t oval_parts_count(const oval_parts* parts);     /* ceil(data_size / part_size) */
+int oval_parts_get(oval_parts* parts, int64_t index, const uint8_t** data, size_t* len,
+                   char* err, size_t err_cap);
+int oval_parts_release(oval_parts* parts, int64_t index);
+void oval_parts_close(oval_parts* parts);
+/* Idle buffers of the pinned pool and the bytes they hold. */
+void oval_parts_pool_stats(size_t* buffers, size_t* bytes);
+
 /* pattern.validDataUnit — pattern.go:136-180.  data holds 256 bytes. */
 int oval_pattern_valid_data_unit(int64_t unit_count, int64_t worker_id,
                                  const char* bucket, size_t bucket_len,

@@ -110,6 +110,12 @@ SIGNATURES = {
     "oval_pattern_valid_batch": (_int, [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "oval_pattern_valid_stream": (_int, [_i64, _cp, _sz, _cp, _sz, _i64, _i64, _vp, _vp, _cp, _sz]),
     "oval_pattern_set_stream_chunk": (None, [_sz]),
+    "oval_pattern_generate_parts": (_int, [_i64, _i64, _cp, _sz, _cp, _sz, _i64, _i64, _pp, _cp, _sz]),
+    "oval_parts_count": (_i64, [_vp]),
+    "oval_parts_get": (_int, [_vp, _i64, _pp, C.POINTER(_sz), _cp, _sz]),
+    "oval_parts_release": (_int, [_vp, _i64]),
+    "oval_parts_close": (None, [_vp]),
+    "oval_parts_pool_stats": (None, [C.POINTER(_sz), C.POINTER(_sz)]),
     "oval_pattern_set_batching": (None, [_int, _int, _sz]),
     "oval_pattern_set_lanes": (None, [_int, _int]),
     "oval_pattern_batching_stats": (None, [C.POINTER(_u64), C.POINTER(_u64)]),

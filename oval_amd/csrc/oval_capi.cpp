@@ -5,12 +5,17 @@
 // OVAL_E_NODEVICE / OVAL_E_HIP, never a silent fallback.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/oval_hip.h"
@@ -44,6 +49,13 @@ struct oval_ctx {
     void*       ring_dev = nullptr;                // kRingSlots slices
     hipEvent_t  ring_ready[kRingSlots] = {};       // slot holds what its consumer waits for
     hipEvent_t  ring_free[kRingSlots] = {};        // slot's consumer is done with it
+    // what else the host-memory entry points need, owned by the context and grow-only
+    oval_layout* host_layout = nullptr;
+    oval_obj_result* host_res_dev = nullptr;
+    uint64_t    host_res_cap = 0;
+    unsigned long long* host_cnt_dev = nullptr;
+    void*       bounce_host = nullptr;             // kRingSlots pinned slices for pageable bodies
+    hipEvent_t  bounce_ev[kRingSlots] = {};        // the copy engine is done with the bounce slot
 };
 
 struct oval_layout {
@@ -223,13 +235,18 @@ int oval_ctx_destroy(oval_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->host_layout) (void)oval_layout_destroy(ctx, ctx->host_layout);
     (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->tallies_dev) (void)hipFree(ctx->tallies_dev);
     if (ctx->ring_dev) (void)hipFree(ctx->ring_dev);
+    if (ctx->host_res_dev) (void)hipFree(ctx->host_res_dev);
+    if (ctx->host_cnt_dev) (void)hipFree(ctx->host_cnt_dev);
+    if (ctx->bounce_host) (void)hipHostFree(ctx->bounce_host);
     for (int i = 0; i < oval_ctx::kRingSlots; ++i) {
         if (ctx->ring_ready[i]) (void)hipEventDestroy(ctx->ring_ready[i]);
         if (ctx->ring_free[i]) (void)hipEventDestroy(ctx->ring_free[i]);
+        if (ctx->bounce_ev[i]) (void)hipEventDestroy(ctx->bounce_ev[i]);
     }
     delete ctx;
     return OVAL_OK;
@@ -628,17 +645,143 @@ int oval_read_unit(oval_ctx* ctx, const void* body_dev, uint64_t byte_offset, ui
     return OVAL_OK;
 }
 
+}  // extern "C"
+
 // ---- bodies in host memory: stage through the device in slices -------------
 // A slice is a whole number of tiles (64 KiB each) and lives in one slot of a
-// small ring of device memory owned by the context, so a call allocates
-// nothing of the size of the batch.  The kernel for slice k runs on the main
+// small ring of device memory owned by the context; the layout, the device-side
+// results and counters and (for pageable bodies) a pinned bounce ring are owned
+// by the context too and only ever grow, so a call allocates nothing once the
+// context has seen a batch of its size.  The kernel for slice k runs on the main
 // stream while the copies of its neighbours run on the copy stream.  A kernel
 // is handed `slot - slice_offset` as the body address: it addresses the body
 // by absolute offset, and exactly the offsets of its slice land in the slot.
+//
+// A pageable body cannot be the end point of an asynchronous copy (the runtime
+// stages it through a small buffer of its own, synchronously: 17-28 GB/s), so
+// it moves between the caller's memory and a pinned bounce slot with a memcpy
+// spread over a few host threads while the copy engine works on the neighbouring
+// slot.
 namespace {
 constexpr uint64_t kTileBytes = (uint64_t)oval::kUnitsPerTile * OVAL_UNIT_SIZE;
 constexpr uint32_t kSliceTiles = 512;   // 32 MiB
 constexpr uint64_t kSliceBytes = kSliceTiles * kTileBytes;
+constexpr size_t kMaxRunsPerSlice = 64;  // more separate bodies than this in a slice: the slice round-trips instead
+constexpr int kCopyHelpers = 7;          // + the calling thread
+constexpr size_t kCopySegBytes = 1u << 20;
+
+struct CopySeg {
+    void* dst;
+    const void* src;
+    size_t n;
+};
+
+// memcpy of a list of segments spread over a few threads; the caller takes part.
+class CopyPool {
+public:
+    static CopyPool& get()
+    {
+        static CopyPool* p = new CopyPool;   // never destroyed: its threads sleep until the process ends
+        return *p;
+    }
+
+    void run(const CopySeg* segs, size_t n)
+    {
+        size_t bytes = 0;
+        for (size_t i = 0; i < n; ++i) bytes += segs[i].n;
+        if (n <= 1 || bytes < (4u << 20)) {
+            for (size_t i = 0; i < n; ++i) std::memcpy(segs[i].dst, segs[i].src, segs[i].n);
+            return;
+        }
+        std::lock_guard<std::mutex> call(call_mu_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (threads_ == 0)
+                for (; threads_ < kCopyHelpers; ++threads_) std::thread([this] { worker(); }).detach();
+            segs_ = segs;
+            n_segs_ = n;
+            next_.store(0, std::memory_order_relaxed);
+            pending_ = threads_;
+            ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+private:
+    void work()
+    {
+        for (;;) {
+            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_segs_) return;
+            std::memcpy(segs_[i].dst, segs_[i].src, segs_[i].n);
+        }
+    }
+
+    void worker()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            lk.unlock();
+            work();
+            lk.lock();
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+
+    std::mutex call_mu_;                 // one parallel copy at a time
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    int threads_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    const CopySeg* segs_ = nullptr;
+    size_t n_segs_ = 0;
+    std::atomic<size_t> next_{0};
+};
+
+void add_segs(std::vector<CopySeg>& out, char* dst, const char* src, uint64_t n)
+{
+    for (uint64_t o = 0; o < n; o += kCopySegBytes)
+        out.push_back(CopySeg{dst + o, src + o, (size_t)(n - o < kCopySegBytes ? n - o : kCopySegBytes)});
+}
+
+// true when `p` is host memory the copy engines can reach directly
+bool is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof a);
+    const hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();         // plain malloc memory is reported as an invalid value
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// The byte ranges of a slice that belong to an object, neighbours merged; walks
+// the (ascending) descriptor array once over all the slices of a call.
+struct RunWalker {
+    const oval_obj_desc* d;
+    uint64_t n, i = 0;
+    void runs(uint64_t b0, uint64_t b1, std::vector<std::pair<uint64_t, uint64_t>>& out)
+    {
+        out.clear();
+        while (i < n && d[i].body_offset + (uint64_t)d[i].n_units * OVAL_UNIT_SIZE <= b0) ++i;
+        for (uint64_t k = i; k < n && d[k].body_offset < b1; ++k) {
+            const uint64_t s = d[k].body_offset > b0 ? d[k].body_offset : b0;
+            uint64_t e = d[k].body_offset + (uint64_t)d[k].n_units * OVAL_UNIT_SIZE;
+            if (e > b1) e = b1;
+            if (e <= s) continue;
+            if (!out.empty() && out.back().second == s) out.back().second = e;
+            else out.emplace_back(s, e);
+        }
+    }
+};
 
 hipError_t ensure_ring(oval_ctx* c)
 {
@@ -652,56 +795,138 @@ hipError_t ensure_ring(oval_ctx* c)
     return e;
 }
 
+hipError_t ensure_bounce(oval_ctx* c)
+{
+    if (c->bounce_host) return hipSuccess;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < oval_ctx::kRingSlots && e == hipSuccess; ++i)
+        if (!c->bounce_ev[i]) e = hipEventCreateWithFlags(&c->bounce_ev[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc(&c->bounce_host, oval_ctx::kRingSlots * kSliceBytes, hipHostMallocDefault);
+    return e;
+}
+
 // the body address that makes absolute offset b0 fall on the start of `slot`
 char* slot_base(const oval_ctx* c, uint32_t slot, uint64_t b0)
 {
     return (char*)c->ring_dev + (uint64_t)slot * kSliceBytes - b0;
 }
+
+char* bounce_slot(const oval_ctx* c, uint32_t slot) { return (char*)c->bounce_host + (uint64_t)slot * kSliceBytes; }
+
+// The context's own layout, reset to `descs`; checks the host body against it.
+int host_layout_for(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, const void* body_host,
+                    uint64_t body_bytes, oval_layout** out)
+{
+    int rc;
+    if (!ctx->host_layout) {
+        if ((rc = oval_layout_create(ctx, nullptr, 0, &ctx->host_layout))) return rc;
+    }
+    oval_layout* l = ctx->host_layout;
+    if ((rc = oval_layout_reset(ctx, l, descs, n_obj))) return rc;
+    if (body_bytes < l->span_bytes || (!body_host && l->span_bytes))
+        return fail(OVAL_E_RANGE, "host body holds %llu bytes but the layout spans %llu",
+                    (unsigned long long)body_bytes, (unsigned long long)l->span_bytes);
+    *out = l;
+    return OVAL_OK;
+}
+
 }  // namespace
+
+uint32_t oval_internal_host_slices(uint64_t span_bytes)
+{
+    return (uint32_t)((span_bytes + kSliceBytes - 1) / kSliceBytes);
+}
+
+uint64_t oval_internal_host_slice_bytes(void) { return kSliceBytes; }
+
+// oval_fill_batch_host, optionally without the final wait: `landed[k]` (if not
+// NULL; then body_host must be pinned) is recorded on the copy stream when slice
+// k, bytes [k * 32 MiB, (k + 1) * 32 MiB) of the body, has arrived in host memory.
+int oval_internal_fill_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, void* body_host,
+                            uint64_t body_bytes, hipEvent_t* landed, uint32_t n_landed, bool wait)
+{
+    if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
+    oval_layout* l = nullptr;
+    int rc = host_layout_for(ctx, descs, n_obj, body_host, body_bytes, &l);
+    if (rc) return rc;
+    if (l->no_fill)
+        return fail(OVAL_E_FIELD, "the batch holds an object whose names do not format to 28 bytes; "
+                                  "the reference's Generate fails for it (pattern.go:87-89)");
+    const uint32_t n_tiles = tiles_of(l);
+    if (landed && n_landed < oval_internal_host_slices(l->span_bytes))
+        return fail(OVAL_E_INVALID, "one event per 32 MiB slice is needed");
+    const bool pinned = landed ? true : (l->span_bytes == 0 || is_pinned(body_host));
+    hipError_t e = ensure_ring(ctx);
+    if (e == hipSuccess && !pinned) e = ensure_bounce(ctx);
+    // Only bytes that belong to an object may change in the caller's buffer:
+    // the kernel writes nothing else into the slot, so gaps are not copied back.
+    const bool contiguous = l->total_units * OVAL_UNIT_SIZE == l->span_bytes;
+    const oval::LayoutView v = view_of(l);
+    RunWalker walker{descs, n_obj};
+    std::vector<std::pair<uint64_t, uint64_t>> runs;
+    constexpr uint32_t kSlots = oval_ctx::kRingSlots, kLag = 2;
+    struct Drain { uint64_t b0; std::vector<CopySeg> segs; };
+    Drain drains[kSlots];
+    auto drain = [&](uint32_t k) {                              // pageable: bounce slot -> caller's memory
+        Drain& d = drains[k % kSlots];
+        hipError_t de = hipEventSynchronize(ctx->bounce_ev[k % kSlots]);
+        if (de == hipSuccess) CopyPool::get().run(d.segs.data(), d.segs.size());
+        return de;
+    };
+    uint32_t k = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles, ++k) {
+        const uint32_t t1 = t0 + kSliceTiles < n_tiles ? t0 + kSliceTiles : n_tiles;
+        const uint32_t slot = k % kSlots;
+        const uint64_t b0 = (uint64_t)t0 * kTileBytes;
+        uint64_t b1 = (uint64_t)t1 * kTileBytes;
+        if (b1 > l->span_bytes) b1 = l->span_bytes;
+        if (contiguous) { runs.clear(); if (b1 > b0) runs.emplace_back(b0, b1); }
+        else walker.runs(b0, b1, runs);
+        const bool round_trip = pinned && runs.size() > kMaxRunsPerSlice;
+        char* const base = slot_base(ctx, slot, b0);
+        // the slot's previous slice must have left for the host
+        if (k >= kSlots) e = hipStreamWaitEvent(ctx->stream, ctx->ring_free[slot], 0);
+        if (e == hipSuccess && round_trip)                      // gaps travel there and back unchanged
+            e = hipMemcpyAsync(base + b0, (const char*)body_host + b0, b1 - b0, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = oval::launch_fill(ctx->stream, cfg_of(ctx), v, base, t0, t1);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ring_ready[slot], ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ring_ready[slot], 0);
+        if (pinned) {
+            if (round_trip) { runs.clear(); runs.emplace_back(b0, b1); }
+            for (size_t r = 0; r < runs.size() && e == hipSuccess; ++r)
+                e = hipMemcpyAsync((char*)body_host + runs[r].first, base + runs[r].first,
+                                   runs[r].second - runs[r].first, hipMemcpyDeviceToHost, ctx->copy_stream);
+        } else {
+            if (e == hipSuccess && b1 > b0)
+                e = hipMemcpyAsync(bounce_slot(ctx, slot), base + b0, b1 - b0, hipMemcpyDeviceToHost, ctx->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->bounce_ev[slot], ctx->copy_stream);
+            Drain& d = drains[slot];
+            d.b0 = b0;
+            d.segs.clear();
+            for (const auto& r : runs)
+                add_segs(d.segs, (char*)body_host + r.first, bounce_slot(ctx, slot) + (r.first - b0), r.second - r.first);
+        }
+        if (e == hipSuccess) e = hipEventRecord(ctx->ring_free[slot], ctx->copy_stream);
+        if (e == hipSuccess && landed) e = hipEventRecord(landed[k], ctx->copy_stream);
+        if (e == hipSuccess && !pinned && k >= kLag) e = drain(k - kLag);
+    }
+    if (!pinned)
+        for (uint32_t q = k > kLag ? k - kLag : 0; q < k && e == hipSuccess; ++q) e = drain(q);
+    if (wait || e != hipSuccess) {
+        const hipError_t e1 = hipStreamSynchronize(ctx->stream);
+        const hipError_t e2 = hipStreamSynchronize(ctx->copy_stream);
+        if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+    }
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "fill_batch_host: %s", hipGetErrorString(e));
+    return OVAL_OK;
+}
+
+extern "C" {
 
 int oval_fill_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, void* body_host,
                          uint64_t body_bytes)
 {
-    if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
-    oval_layout* l = nullptr;
-    int rc = oval_layout_create(ctx, descs, n_obj, &l);
-    if (rc) return rc;
-    if (body_bytes < l->span_bytes || (!body_host && l->span_bytes)) {
-        oval_layout_destroy(ctx, l);
-        return fail(OVAL_E_RANGE, "host body holds %llu bytes but the layout spans %llu",
-                    (unsigned long long)body_bytes, (unsigned long long)l->span_bytes);
-    }
-    if (l->no_fill) {
-        oval_layout_destroy(ctx, l);
-        return fail(OVAL_E_FIELD, "the batch holds an object whose names do not format to 28 bytes; "
-                                  "the reference's Generate fails for it (pattern.go:87-89)");
-    }
-    hipError_t e = ensure_ring(ctx);
-    const uint32_t n_tiles = tiles_of(l);
-    const oval::LayoutView v = view_of(l);
-    uint32_t k = 0;
-    for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles, ++k) {
-        const uint32_t t1 = t0 + kSliceTiles < n_tiles ? t0 + kSliceTiles : n_tiles;
-        const uint32_t slot = k % oval_ctx::kRingSlots;
-        const uint64_t b0 = (uint64_t)t0 * kTileBytes;
-        uint64_t b1 = (uint64_t)t1 * kTileBytes;
-        if (b1 > l->span_bytes) b1 = l->span_bytes;
-        // the slot's previous slice must have left for the host
-        if (k >= (uint32_t)oval_ctx::kRingSlots) e = hipStreamWaitEvent(ctx->stream, ctx->ring_free[slot], 0);
-        if (e == hipSuccess) e = oval::launch_fill(ctx->stream, cfg_of(ctx), v, slot_base(ctx, slot, b0), t0, t1);
-        if (e == hipSuccess) e = hipEventRecord(ctx->ring_ready[slot], ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ring_ready[slot], 0);
-        if (e == hipSuccess && b1 > b0)
-            e = hipMemcpyAsync((char*)body_host + b0, slot_base(ctx, slot, b0) + b0, b1 - b0, hipMemcpyDeviceToHost,
-                               ctx->copy_stream);
-        if (e == hipSuccess) e = hipEventRecord(ctx->ring_free[slot], ctx->copy_stream);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    const hipError_t e2 = hipStreamSynchronize(ctx->copy_stream);
-    if (e == hipSuccess) e = e2;
-    oval_layout_destroy(ctx, l);
-    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "fill_batch_host: %s", hipGetErrorString(e));
-    return OVAL_OK;
+    return oval_internal_fill_host(ctx, descs, n_obj, body_host, body_bytes, nullptr, 0, true);
 }
 
 int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj,
@@ -710,34 +935,49 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
 {
     if (!ctx || (!results_host && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
     oval_layout* l = nullptr;
-    int rc = oval_layout_create(ctx, descs, n_obj, &l);
+    int rc = host_layout_for(ctx, descs, n_obj, body_host, body_bytes, &l);
     if (rc) return rc;
-    if (body_bytes < l->span_bytes || (!body_host && l->span_bytes)) {
-        oval_layout_destroy(ctx, l);
-        return fail(OVAL_E_RANGE, "host body holds %llu bytes but the layout spans %llu",
-                    (unsigned long long)body_bytes, (unsigned long long)l->span_bytes);
-    }
-    oval_obj_result* res_dev = nullptr;
-    unsigned long long* cnt_dev = nullptr;
+    const bool pinned = l->span_bytes == 0 || is_pinned(body_host);
     hipError_t e = ensure_ring(ctx);
-    if (e == hipSuccess) e = hipMalloc((void**)&res_dev, n_obj ? n_obj * sizeof(oval_obj_result) : 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&cnt_dev, OVAL_NUM_COUNTERS * 8);
+    if (e == hipSuccess && !pinned) e = ensure_bounce(ctx);
+    if (e == hipSuccess && (n_obj > ctx->host_res_cap || !ctx->host_res_dev)) {
+        if (ctx->host_res_dev) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->host_res_dev); }
+        ctx->host_res_dev = nullptr; ctx->host_res_cap = 0;
+        const uint64_t cap = n_obj < 1024 ? 1024 : n_obj + n_obj / 8;
+        e = hipMalloc((void**)&ctx->host_res_dev, cap * sizeof(oval_obj_result));
+        if (e == hipSuccess) ctx->host_res_cap = cap;
+    }
+    if (e == hipSuccess && !ctx->host_cnt_dev) e = hipMalloc((void**)&ctx->host_cnt_dev, OVAL_NUM_COUNTERS * 8);
+    oval_obj_result* const res_dev = ctx->host_res_dev;
+    unsigned long long* const cnt_dev = ctx->host_cnt_dev;
     if (e == hipSuccess) e = hipMemsetAsync(cnt_dev, 0, OVAL_NUM_COUNTERS * 8, ctx->stream);
     const uint32_t n_tiles = tiles_of(l);
     const oval::LayoutView v = view_of(l);
     if (e == hipSuccess) e = oval::launch_init_results(ctx->stream, v, res_dev, cnt_dev);
+    constexpr uint32_t kSlots = oval_ctx::kRingSlots;
+    std::vector<CopySeg> segs;
     uint32_t k = 0;
     for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles, ++k) {
         const uint32_t t1 = t0 + kSliceTiles < n_tiles ? t0 + kSliceTiles : n_tiles;
-        const uint32_t slot = k % oval_ctx::kRingSlots;
+        const uint32_t slot = k % kSlots;
         const uint64_t b0 = (uint64_t)t0 * kTileBytes;
         uint64_t b1 = (uint64_t)t1 * kTileBytes;
         if (b1 > l->span_bytes) b1 = l->span_bytes;
+        const char* src = (const char*)body_host + b0;
+        if (!pinned && b1 > b0) {
+            // the bounce slot's previous slice must have left for the device
+            if (k >= kSlots) e = hipEventSynchronize(ctx->bounce_ev[slot]);
+            if (e != hipSuccess) break;
+            segs.clear();
+            add_segs(segs, bounce_slot(ctx, slot), src, b1 - b0);
+            CopyPool::get().run(segs.data(), segs.size());
+            src = bounce_slot(ctx, slot);
+        }
         // the slot's previous slice must have been validated
-        if (k >= (uint32_t)oval_ctx::kRingSlots) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ring_free[slot], 0);
+        if (k >= kSlots) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ring_free[slot], 0);
         if (e == hipSuccess && b1 > b0)
-            e = hipMemcpyAsync(slot_base(ctx, slot, b0) + b0, (const char*)body_host + b0, b1 - b0,
-                               hipMemcpyHostToDevice, ctx->copy_stream);
+            e = hipMemcpyAsync(slot_base(ctx, slot, b0) + b0, src, b1 - b0, hipMemcpyHostToDevice, ctx->copy_stream);
+        if (e == hipSuccess && !pinned) e = hipEventRecord(ctx->bounce_ev[slot], ctx->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(ctx->ring_ready[slot], ctx->copy_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ring_ready[slot], 0);
         if (e == hipSuccess)
@@ -749,14 +989,16 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
         e = hipMemcpyAsync(results_host, res_dev, n_obj * sizeof(oval_obj_result), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && counters_host)
         e = hipMemcpyAsync(counters_host, cnt_dev, OVAL_NUM_COUNTERS * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->copy_stream);
-    if (res_dev) (void)hipFree(res_dev);
-    if (cnt_dev) (void)hipFree(cnt_dev);
-    oval_layout_destroy(ctx, l);
+    const hipError_t e1 = hipStreamSynchronize(ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->copy_stream);
+    if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "validate_batch_host: %s", hipGetErrorString(e));
     return OVAL_OK;
 }
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- timing -----------------------------------------------------------------
 int oval_timer_create(oval_ctx* ctx, oval_timer** out)

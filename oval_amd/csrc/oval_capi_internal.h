@@ -9,3 +9,14 @@
 int oval_internal_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int oval_internal_ctx_device(const oval_ctx* ctx);
 hipStream_t oval_internal_ctx_stream(const oval_ctx* ctx);
+
+// The host-memory fill behind oval_fill_batch_host, optionally without the final
+// wait: landed[k] (then body_host must be pinned and n_landed >= the number of
+// slices) is recorded when slice k of the body, bytes [k * slice, (k + 1) * slice),
+// has arrived in host memory.  Uses the context's own layout and staging ring,
+// so the context must not start another host-memory call until the last event
+// has completed.
+int oval_internal_fill_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, void* body_host,
+                            uint64_t body_bytes, hipEvent_t* landed, uint32_t n_landed, bool wait);
+uint32_t oval_internal_host_slices(uint64_t span_bytes);
+uint64_t oval_internal_host_slice_bytes(void);

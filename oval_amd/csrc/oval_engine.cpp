@@ -152,6 +152,8 @@ struct Pipeline {
 
 Pipeline g;
 
+void pool_drop_all();                     // pinned buffers of the generated-parts pool (below)
+
 int slot_fail(Slot& s, int rc)
 {
     s.err = oval_last_error();
@@ -657,6 +659,7 @@ void shutdown()
     g.slot_cv.wait(lk, [] { return !g.inited || g.free_slots.size() == (size_t)kSlots; });
     g.slot_waiters--;
     for (Slot& s : g.slots) destroy_slot(s);
+    pool_drop_all();
 }
 
 // ---------------------------------------------------------------------------
@@ -720,6 +723,214 @@ void stream_close(Stream* st)
     (void)oval_ctx_sync(st->s->ctx);
     release_slot(st->s);
     delete st;
+}
+
+// ---------------------------------------------------------------------------
+// generated parts
+// ---------------------------------------------------------------------------
+namespace {
+
+// Idle pinned buffers.  Pinning memory costs milliseconds per 100 MB, far more
+// than generating into it, so buffers are reused; what is kept idle is bounded.
+constexpr size_t kPoolKeepBytes = 2ull << 30;
+constexpr size_t kPoolKeepBuffers = 16;
+
+struct PinnedBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+};
+
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<PinnedBuf> idle;
+    size_t idle_bytes = 0;
+};
+
+PinnedPool g_pool;
+
+// The smallest idle buffer that fits, or a new one (capacity rounded up so that
+// bodies of similar size share buffers).
+bool pool_take(size_t bytes, PinnedBuf* out, std::string* err)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        size_t best = g_pool.idle.size();
+        for (size_t i = 0; i < g_pool.idle.size(); ++i)
+            if (g_pool.idle[i].cap >= bytes && (best == g_pool.idle.size() || g_pool.idle[i].cap < g_pool.idle[best].cap))
+                best = i;
+        if (best != g_pool.idle.size() && g_pool.idle[best].cap <= 2 * bytes + (1u << 20)) {
+            *out = g_pool.idle[best];
+            g_pool.idle_bytes -= out->cap;
+            g_pool.idle.erase(g_pool.idle.begin() + (long)best);
+            return true;
+        }
+    }
+    size_t cap = 1u << 20;
+    while (cap < bytes) cap += cap < (64u << 20) ? cap : (64u << 20);   // doubles up to 64 MiB, then 64 MiB steps
+    void* p = nullptr;
+    (void)hipSetDevice(g.device);
+    const hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        if (err) *err = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        return false;
+    }
+    out->p = static_cast<uint8_t*>(p);
+    out->cap = cap;
+    return true;
+}
+
+void pool_give(const PinnedBuf& b)
+{
+    if (!b.p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        if (g_pool.idle.size() < kPoolKeepBuffers && g_pool.idle_bytes + b.cap <= kPoolKeepBytes) {
+            g_pool.idle.push_back(b);
+            g_pool.idle_bytes += b.cap;
+            return;
+        }
+    }
+    (void)hipHostFree(b.p);
+}
+
+void pool_drop_all()
+{
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (const PinnedBuf& b : g_pool.idle) (void)hipHostFree(b.p);
+    g_pool.idle.clear();
+    g_pool.idle_bytes = 0;
+}
+
+}  // namespace
+
+struct Parts {
+    Slot* s = nullptr;                    // held until the last slice has landed
+    PinnedBuf buf;
+    size_t bytes = 0;
+    std::vector<hipEvent_t> landed;       // one per staging slice
+    std::mutex mu;
+    uint32_t landed_upto = 0;             // slices known to have arrived
+    std::string err;
+};
+
+namespace {
+
+// p->mu held.  Waits for slices [landed_upto, upto) and hands the slot back once
+// the last one is in.
+bool parts_advance(Parts* p, uint32_t upto)
+{
+    if (upto > p->landed_upto) {
+        const hipError_t e = hipEventSynchronize(p->landed[upto - 1]);   // the copy stream completes them in order
+        if (e != hipSuccess) {
+            p->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e);
+            return false;
+        }
+        p->landed_upto = upto;
+    }
+    if (p->s && p->landed_upto == p->landed.size()) {
+        release_slot(p->s);
+        p->s = nullptr;
+    }
+    return true;
+}
+
+}  // namespace
+
+Parts* parts_open(const oval_obj_desc& desc, std::string* err)
+{
+    Parts* p = new Parts;
+    p->bytes = (size_t)desc.n_units * kUnit;
+    if (!pool_take(p->bytes ? p->bytes : 1, &p->buf, err)) {
+        delete p;
+        return nullptr;
+    }
+    if (p->bytes == 0) return p;
+    if (p->bytes <= kSharedJobMax) {
+        // small enough to share a launch with other callers' jobs
+        Job job;
+        job.is_fill = true;
+        job.desc = desc;
+        job.out = p->buf.p;
+        execute(job);
+        if (job.failed) {
+            if (err) *err = job.err;
+            pool_give(p->buf);
+            delete p;
+            return nullptr;
+        }
+        return p;
+    }
+    Slot* s = acquire_slot();
+    reset_batch(*s);
+    int rc = ensure_slot(*s, 0, 0, 0);
+    const uint32_t n_slices = oval_internal_host_slices(p->bytes);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        p->landed.resize(n_slices, nullptr);
+        for (uint32_t i = 0; i < n_slices && e == hipSuccess; ++i)
+            e = hipEventCreateWithFlags(&p->landed[i], hipEventDisableTiming);
+        if (e != hipSuccess) rc = hip_fail(*s, e, "hipEventCreate");
+    }
+    if (!rc) {
+        oval_obj_desc d = desc;
+        d.body_offset = 0;
+        rc = oval_internal_fill_host(s->ctx, &d, 1, p->buf.p, p->bytes, p->landed.data(), n_slices, false);
+        if (rc) slot_fail(*s, rc);
+    }
+    if (rc) {
+        note_failure(*s);
+        if (err) *err = s->err;
+        if (s->ctx) (void)oval_ctx_sync(s->ctx);
+        release_slot(s);
+        for (hipEvent_t ev : p->landed)
+            if (ev) (void)hipEventDestroy(ev);
+        pool_give(p->buf);
+        delete p;
+        return nullptr;
+    }
+    p->s = s;
+    return p;
+}
+
+const uint8_t* parts_wait(Parts* p, size_t begin, size_t end, std::string* err)
+{
+    (void)begin;
+    if (end > p->bytes) end = p->bytes;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->landed.empty() && end > 0) {
+        const uint64_t slice = oval_internal_host_slice_bytes();
+        const uint32_t upto = (uint32_t)((end + slice - 1) / slice);
+        if (!parts_advance(p, upto)) {
+            if (err) *err = p->err;
+            return nullptr;
+        }
+    }
+    return p->buf.p;
+}
+
+void parts_close(Parts* p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        // copies still in flight write into the buffer: they must finish before it is reused
+        if (!parts_advance(p, (uint32_t)p->landed.size()) && p->s) {
+            (void)oval_ctx_sync(p->s->ctx);
+            release_slot(p->s);
+            p->s = nullptr;
+        }
+    }
+    for (hipEvent_t ev : p->landed)
+        if (ev) (void)hipEventDestroy(ev);
+    pool_give(p->buf);
+    delete p;
+}
+
+void parts_pool_stats(size_t* buffers, size_t* bytes)
+{
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    if (buffers) *buffers = g_pool.idle.size();
+    if (bytes) *bytes = g_pool.idle_bytes;
 }
 
 }  // namespace engine

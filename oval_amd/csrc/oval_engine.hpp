@@ -59,5 +59,18 @@ int stream_wait(Stream* st, int half, oval_obj_result* res);
 std::string stream_error(Stream* st);
 void stream_close(Stream* st);
 
+// A generated body that arrives in library-owned pinned memory slice by slice
+// (what a multipart upload sends part by part, internal/s3client/s3client.go:164-236):
+// parts_open starts the fill and returns at once; parts_wait blocks until bytes
+// [begin, end) of the body have landed and returns the start of the buffer.
+// The buffer comes from a pool of pinned allocations and goes back to it in
+// parts_close.
+struct Parts;
+Parts* parts_open(const oval_obj_desc& desc, std::string* err);
+const uint8_t* parts_wait(Parts* p, size_t begin, size_t end, std::string* err);   // NULL on engine failure
+void parts_close(Parts* p);
+// Idle pinned buffers the pool keeps / bytes they hold (for tests and tools).
+void parts_pool_stats(size_t* buffers, size_t* bytes);
+
 }  // namespace engine
 }  // namespace oval

@@ -381,6 +381,83 @@ std::vector<Error> GenerateBatch(const std::vector<GenerateItem>& items)
 }
 
 // ---------------------------------------------------------------------------
+// GenerateParts — Generate (pattern.go:73-92) whose result is consumed in parts
+// (internal/s3client/s3client.go:164-236)
+// ---------------------------------------------------------------------------
+std::pair<GeneratedParts*, Error> GenerateParts(int64_t dataSize, int64_t workerID, const std::string& bucketName,
+                                                const object::Object* obj, int64_t partSize)
+{
+    if (partSize <= 0) return {nullptr, Error::New("oval engine failure: part size must be positive")};
+    Job job;
+    Error err = prepare_generate(dataSize, workerID, bucketName, obj, nullptr, job);
+    if (!err.nil()) return {nullptr, err};
+    std::string eng_err;
+    engine::Parts* impl = engine::parts_open(job.desc, &eng_err);
+    if (!impl) return {nullptr, Error::New("oval engine failure: " + eng_err)};
+    GeneratedParts* p = new GeneratedParts;
+    p->impl_ = impl;
+    p->size_ = (int64_t)job.desc.n_units * dataUnitSize;
+    p->part_size_ = partSize;
+    p->count_ = (p->size_ + partSize - 1) / partSize;
+    p->outstanding_ = p->count_;
+    p->state_.assign((size_t)p->count_, 0);
+    p->mu_ = new std::mutex;
+    if (p->count_ == 0) p->Close();                          // nothing to hand out
+    return {p, Error::Nil()};
+}
+
+GeneratedParts::~GeneratedParts()
+{
+    Close();
+    delete static_cast<std::mutex*>(mu_);
+}
+
+Error GeneratedParts::Part(int64_t i, const uint8_t** data, size_t* len)
+{
+    if (i < 0 || i >= count_) return Error::New("oval engine failure: part index out of range");
+    engine::Parts* impl;
+    {
+        std::lock_guard<std::mutex> lk(*static_cast<std::mutex*>(mu_));
+        if (!impl_ || state_[(size_t)i] == 2) return Error::New("oval engine failure: part already released");
+        state_[(size_t)i] = 1;
+        impl = static_cast<engine::Parts*>(impl_);
+    }
+    const size_t begin = (size_t)(i * part_size_);
+    const size_t end = (size_t)std::min<int64_t>(size_, (i + 1) * part_size_);
+    std::string eng_err;
+    const uint8_t* base = engine::parts_wait(impl, begin, end, &eng_err);
+    if (!base) return Error::New("oval engine failure: " + eng_err);
+    *data = base + begin;
+    *len = end - begin;
+    return Error::Nil();
+}
+
+Error GeneratedParts::Release(int64_t i)
+{
+    if (i < 0 || i >= count_) return Error::New("oval engine failure: part index out of range");
+    bool last = false;
+    {
+        std::lock_guard<std::mutex> lk(*static_cast<std::mutex*>(mu_));
+        if (!impl_ || state_[(size_t)i] == 2) return Error::Nil();   // releasing twice is harmless
+        state_[(size_t)i] = 2;
+        last = --outstanding_ == 0;
+    }
+    if (last) Close();
+    return Error::Nil();
+}
+
+void GeneratedParts::Close()
+{
+    engine::Parts* impl = nullptr;
+    if (mu_) {
+        std::lock_guard<std::mutex> lk(*static_cast<std::mutex*>(mu_));
+        impl = static_cast<engine::Parts*>(impl_);
+        impl_ = nullptr;
+    }
+    if (impl) engine::parts_close(impl);
+}
+
+// ---------------------------------------------------------------------------
 // generateDataUnit — pattern.go:94-116
 // ---------------------------------------------------------------------------
 std::pair<std::vector<uint8_t>, Error> generateDataUnit(int64_t unitCount, int64_t workerID,
@@ -885,6 +962,40 @@ int oval_pattern_valid_stream(int64_t worker_id, const char* bucket, size_t buck
 }
 
 void oval_pattern_set_stream_chunk(size_t bytes) { oval::pattern::SetStreamChunkBytes(bytes); }
+
+int oval_pattern_generate_parts(int64_t data_size, int64_t worker_id, const char* bucket, size_t bucket_len,
+                                const char* key, size_t key_len, int64_t write_count, int64_t part_size,
+                                oval_parts** out, char* err, size_t err_cap)
+{
+    if (out) *out = nullptr;
+    if (!out) return put_error(oval::Error::New("oval engine failure: out is NULL"), err, err_cap);
+    const oval::object::Object obj = make_obj(key, key_len, 0, write_count);
+    const std::string b(bucket ? bucket : "", bucket_len);
+    auto r = oval::pattern::GenerateParts(data_size, worker_id, b, &obj, part_size);
+    *out = reinterpret_cast<oval_parts*>(r.first);
+    return put_error(r.second, err, err_cap);
+}
+
+int64_t oval_parts_count(const oval_parts* parts)
+{
+    return parts ? reinterpret_cast<const oval::pattern::GeneratedParts*>(parts)->Count() : 0;
+}
+
+int oval_parts_get(oval_parts* parts, int64_t index, const uint8_t** data, size_t* len, char* err, size_t err_cap)
+{
+    if (!parts || !data || !len) return put_error(oval::Error::New("oval engine failure: NULL argument"), err, err_cap);
+    return put_error(reinterpret_cast<oval::pattern::GeneratedParts*>(parts)->Part(index, data, len), err, err_cap);
+}
+
+int oval_parts_release(oval_parts* parts, int64_t index)
+{
+    if (!parts) return OVAL_E_INVALID;
+    return reinterpret_cast<oval::pattern::GeneratedParts*>(parts)->Release(index).nil() ? 0 : OVAL_E_INVALID;
+}
+
+void oval_parts_close(oval_parts* parts) { delete reinterpret_cast<oval::pattern::GeneratedParts*>(parts); }
+
+void oval_parts_pool_stats(size_t* buffers, size_t* bytes) { oval::engine::parts_pool_stats(buffers, bytes); }
 
 void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes)
 {

@@ -83,6 +83,40 @@ std::pair<std::vector<uint8_t>, Error> Generate(int64_t dataSize, int64_t worker
 Error GenerateInto(int64_t dataSize, int64_t workerID, const std::string& bucketName,
                    const object::Object* obj, uint8_t* out);
 
+// Generate for a body that leaves in parts.  The reference's multipartUpload
+// (internal/s3client/s3client.go:164-236) re-slices the []byte Generate returned
+// into parts of multipartThresh bytes (body[:partSize] at :185, body =
+// body[partSize:] at :204) and sends them one after the other.  Here the body is
+// generated once into pinned memory owned by the library (no copy into caller
+// memory) and arrives there slice by slice while earlier parts are already on
+// their way out: Part(i) waits only for the bytes of part i.
+class GeneratedParts {
+public:
+    ~GeneratedParts();
+    int64_t Size() const { return size_; }
+    int64_t PartSize() const { return part_size_; }
+    int64_t Count() const { return count_; }          // ceil(Size / PartSize): the UploadPart calls of :176-211
+    // body[i*PartSize : min((i+1)*PartSize, Size)]; valid until Release(i) or Close().
+    Error Part(int64_t i, const uint8_t** data, size_t* len);
+    // The caller is done with part i.  When every part has been released the
+    // pinned buffer goes back to the library's pool.
+    Error Release(int64_t i);
+    // Gives up whatever is still held (the abort path, s3client.go:190-203).
+    void Close();
+private:
+    friend std::pair<GeneratedParts*, Error> GenerateParts(int64_t, int64_t, const std::string&,
+                                                            const object::Object*, int64_t);
+    GeneratedParts() = default;
+    void* impl_ = nullptr;
+    int64_t size_ = 0, part_size_ = 0, count_ = 0, outstanding_ = 0;
+    std::vector<uint8_t> state_;                       // per part: 0 not handed out, 1 handed out, 2 released
+    void* mu_ = nullptr;
+};
+// Errors are Generate's (pattern.go:87-89); partSize must be positive.  The
+// caller owns the returned object (delete it, or Close() and delete).
+std::pair<GeneratedParts*, Error> GenerateParts(int64_t dataSize, int64_t workerID, const std::string& bucketName,
+                                                const object::Object* obj, int64_t partSize);
+
 // pattern.go:94-116
 std::pair<std::vector<uint8_t>, Error> generateDataUnit(int64_t unitCount, int64_t workerID,
                                                         const std::string& bucketName,

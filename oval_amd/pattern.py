@@ -75,6 +75,63 @@ def Generate(dataSize: int, workerID: int, bucketName, obj: Object) -> bytes:
     return out[:dataSize].tobytes()
 
 
+class GeneratedParts:
+    """Generate whose result leaves in parts (the reference's multipartUpload,
+    internal/s3client/s3client.go:164-236, slices body[:partSize] at :185 and
+    body = body[partSize:] at :204): one fill into pinned memory owned by the
+    library, part views handed out of it and released one by one."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __len__(self) -> int:
+        return _lib.lib().oval_parts_count(self._h) if self._h else 0
+
+    def part(self, i: int) -> np.ndarray:
+        """A view (not a copy) of part i; valid until release(i) / close()."""
+        data, n = C.c_void_p(), C.c_size_t()
+        err = C.create_string_buffer(_ERR_CAP)
+        rc = _lib.lib().oval_parts_get(self._h, i, C.byref(data), C.byref(n), err, _ERR_CAP)
+        _raise(rc, err)
+        if n.value == 0:
+            return np.empty(0, dtype=np.uint8)
+        return np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint8)), shape=(n.value,))
+
+    def release(self, i: int) -> None:
+        _lib.check(_lib.lib().oval_parts_release(self._h, i))
+
+    def close(self) -> None:
+        if self._h:
+            _lib.lib().oval_parts_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+
+def GenerateParts(dataSize: int, workerID: int, bucketName, obj: Object, partSize: int) -> GeneratedParts:
+    """pattern.go:73-92 for a body that is uploaded in parts of partSize bytes."""
+    b, k = _b(bucketName), _b(obj.Key)
+    h = C.c_void_p()
+    err = C.create_string_buffer(_ERR_CAP)
+    rc = _lib.lib().oval_pattern_generate_parts(dataSize, workerID, b, len(b), k, len(k), obj.WriteCount, partSize,
+                                                C.byref(h), err, _ERR_CAP)
+    _raise(rc, err)
+    return GeneratedParts(h)
+
+
+def parts_pool_stats():
+    n, nbytes = C.c_size_t(), C.c_size_t()
+    _lib.lib().oval_parts_pool_stats(C.byref(n), C.byref(nbytes))
+    return n.value, nbytes.value
+
+
 def generateDataUnit(unitCount: int, workerID: int, bucketName, obj: Object) -> bytes:
     """pattern.go:94-116"""
     b, k = _b(bucketName), _b(obj.Key)
