@@ -41,6 +41,7 @@ struct oval_ctx {
     hipStream_t stream      = nullptr;
     bool        own_stream  = false;
     hipStream_t copy_stream = nullptr;   // second stream for overlapped host copies
+    hipStream_t copy_stream2 = nullptr;  // odd slices of the host-memory entry points copy here: two copy engines at work
     int         fill_threads = 256;    // workgroup sizes of the two kernels
     int         validate_threads = 256;
     unsigned long long* tallies_dev = nullptr;   // striped bad-unit tallies of the validate kernels, zero between passes
@@ -109,6 +110,7 @@ int oval_internal_fail(int code, const char* fmt, ...)
     g_err = buf;
     return code;
 }
+void oval_internal_parallel_copy(void* dst, const void* src, size_t n);   // memcpy, on several threads when large
 int oval_internal_ctx_device(const oval_ctx* ctx) { return ctx->device; }
 hipStream_t oval_internal_ctx_stream(const oval_ctx* ctx) { return ctx->stream; }
 
@@ -207,10 +209,12 @@ int oval_ctx_create(int device_id, void* stream, oval_ctx** out)
         delete c;
         return fail(OVAL_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    e = hipMalloc((void**)&c->tallies_dev, oval::kTallyBytes);
+    e = hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->tallies_dev, oval::kTallyBytes);
     if (e == hipSuccess) e = hipMemset(c->tallies_dev, 0, oval::kTallyBytes);
     if (e != hipSuccess) {
         if (c->tallies_dev) (void)hipFree(c->tallies_dev);
+        if (c->copy_stream2) (void)hipStreamDestroy(c->copy_stream2);
         (void)hipStreamDestroy(c->copy_stream);
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c;
@@ -220,6 +224,7 @@ int oval_ctx_create(int device_id, void* stream, oval_ctx** out)
     e = oval::noalloc_scratch_init(device_id);
     if (e != hipSuccess) {
         (void)hipFree(c->tallies_dev);
+        (void)hipStreamDestroy(c->copy_stream2);
         (void)hipStreamDestroy(c->copy_stream);
         if (c->own_stream) (void)hipStreamDestroy(c->stream);
         delete c;
@@ -235,8 +240,10 @@ int oval_ctx_destroy(oval_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(ctx->copy_stream2);
     if (ctx->host_layout) (void)oval_layout_destroy(ctx, ctx->host_layout);
     (void)hipStreamDestroy(ctx->copy_stream);
+    (void)hipStreamDestroy(ctx->copy_stream2);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->tallies_dev) (void)hipFree(ctx->tallies_dev);
     if (ctx->ring_dev) (void)hipFree(ctx->ring_dev);
@@ -484,7 +491,7 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
             HIP_TRY(hipHostMalloc(&l->stage_host, n_obj * sizeof(oval_obj_desc), hipHostMallocDefault));
             l->cap_stage = n_obj;
         }
-        std::memcpy(l->stage_host, descs, n_obj * sizeof(oval_obj_desc));
+        oval_internal_parallel_copy(l->stage_host, descs, n_obj * sizeof(oval_obj_desc));
         oval_obj_desc* staged = static_cast<oval_obj_desc*>(l->stage_host);
         const uint16_t slow_bits = OVAL_DESC_BUCKET_SLOW | OVAL_DESC_KEY_SLOW;
         for (uint64_t i : fix) staged[i].flags = (uint16_t)((staged[i].flags & ~slow_bits) | slow_flags_of(staged[i]));
@@ -832,6 +839,13 @@ int host_layout_for(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, c
 
 }  // namespace
 
+void oval_internal_parallel_copy(void* dst, const void* src, size_t n)
+{
+    std::vector<CopySeg> segs;
+    add_segs(segs, (char*)dst, (const char*)src, n);
+    CopyPool::get().run(segs.data(), segs.size());
+}
+
 uint32_t oval_internal_host_slices(uint64_t span_bytes)
 {
     return (uint32_t)((span_bytes + kSliceBytes - 1) / kSliceBytes);
@@ -884,30 +898,31 @@ int oval_internal_fill_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t 
         else walker.runs(b0, b1, runs);
         const bool round_trip = pinned && runs.size() > kMaxRunsPerSlice;
         char* const base = slot_base(ctx, slot, b0);
+        const hipStream_t cs = (k & 1) ? ctx->copy_stream2 : ctx->copy_stream;
         // the slot's previous slice must have left for the host
         if (k >= kSlots) e = hipStreamWaitEvent(ctx->stream, ctx->ring_free[slot], 0);
         if (e == hipSuccess && round_trip)                      // gaps travel there and back unchanged
             e = hipMemcpyAsync(base + b0, (const char*)body_host + b0, b1 - b0, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = oval::launch_fill(ctx->stream, cfg_of(ctx), v, base, t0, t1);
         if (e == hipSuccess) e = hipEventRecord(ctx->ring_ready[slot], ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ring_ready[slot], 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(cs, ctx->ring_ready[slot], 0);
         if (pinned) {
             if (round_trip) { runs.clear(); runs.emplace_back(b0, b1); }
             for (size_t r = 0; r < runs.size() && e == hipSuccess; ++r)
                 e = hipMemcpyAsync((char*)body_host + runs[r].first, base + runs[r].first,
-                                   runs[r].second - runs[r].first, hipMemcpyDeviceToHost, ctx->copy_stream);
+                                   runs[r].second - runs[r].first, hipMemcpyDeviceToHost, cs);
         } else {
             if (e == hipSuccess && b1 > b0)
-                e = hipMemcpyAsync(bounce_slot(ctx, slot), base + b0, b1 - b0, hipMemcpyDeviceToHost, ctx->copy_stream);
-            if (e == hipSuccess) e = hipEventRecord(ctx->bounce_ev[slot], ctx->copy_stream);
+                e = hipMemcpyAsync(bounce_slot(ctx, slot), base + b0, b1 - b0, hipMemcpyDeviceToHost, cs);
+            if (e == hipSuccess) e = hipEventRecord(ctx->bounce_ev[slot], cs);
             Drain& d = drains[slot];
             d.b0 = b0;
             d.segs.clear();
             for (const auto& r : runs)
                 add_segs(d.segs, (char*)body_host + r.first, bounce_slot(ctx, slot) + (r.first - b0), r.second - r.first);
         }
-        if (e == hipSuccess) e = hipEventRecord(ctx->ring_free[slot], ctx->copy_stream);
-        if (e == hipSuccess && landed) e = hipEventRecord(landed[k], ctx->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ring_free[slot], cs);
+        if (e == hipSuccess && landed) e = hipEventRecord(landed[k], cs);
         if (e == hipSuccess && !pinned && k >= kLag) e = drain(k - kLag);
     }
     if (!pinned)
@@ -915,7 +930,8 @@ int oval_internal_fill_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t 
     if (wait || e != hipSuccess) {
         const hipError_t e1 = hipStreamSynchronize(ctx->stream);
         const hipError_t e2 = hipStreamSynchronize(ctx->copy_stream);
-        if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+        const hipError_t e3 = hipStreamSynchronize(ctx->copy_stream2);
+        if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3;
     }
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "fill_batch_host: %s", hipGetErrorString(e));
     return OVAL_OK;
@@ -933,13 +949,58 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
                              const void* body_host, uint64_t body_bytes, oval_obj_result* results_host,
                              uint64_t* counters_host)
 {
-    if (!ctx || (!results_host && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
-    oval_layout* l = nullptr;
-    int rc = host_layout_for(ctx, descs, n_obj, body_host, body_bytes, &l);
-    if (rc) return rc;
-    const bool pinned = l->span_bytes == 0 || is_pinned(body_host);
+    if (!ctx || (!results_host && n_obj) || (!descs && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
+    // Where the bodies end follows from the last descriptor (the table ascends;
+    // the layout build below checks that it does).  The first slices start their
+    // way to the device before the descriptor table is even looked at: scanning
+    // and staging a million descriptors takes the host several milliseconds.
+    const uint64_t span = n_obj ? descs[n_obj - 1].body_offset + (uint64_t)descs[n_obj - 1].n_units * OVAL_UNIT_SIZE : 0;
+    if (body_bytes < span || (!body_host && span))
+        return fail(OVAL_E_RANGE, "host body holds %llu bytes but the layout spans %llu",
+                    (unsigned long long)body_bytes, (unsigned long long)span);
+    if (span / OVAL_UNIT_SIZE >= 0xFFFFFF00ull)
+        return fail(OVAL_E_LAYOUT, "batch spans %llu bytes; the limit is just under 1 TiB", (unsigned long long)span);
+    const bool pinned = span == 0 || is_pinned(body_host);
     hipError_t e = ensure_ring(ctx);
     if (e == hipSuccess && !pinned) e = ensure_bounce(ctx);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "validate_batch_host: %s", hipGetErrorString(e));
+    constexpr uint32_t kSlots = oval_ctx::kRingSlots;
+    const uint32_t n_slices = oval_internal_host_slices(span);
+    std::vector<CopySeg> segs;
+    // slice k on its way into ring slot k % kSlots
+    auto upload = [&](uint32_t k) {
+        const uint32_t slot = k % kSlots;
+        const uint64_t b0 = (uint64_t)k * kSliceBytes;
+        const uint64_t b1 = b0 + kSliceBytes < span ? b0 + kSliceBytes : span;
+        const char* src = (const char*)body_host + b0;
+        const hipStream_t cs = (k & 1) ? ctx->copy_stream2 : ctx->copy_stream;
+        hipError_t ue = hipSuccess;
+        if (!pinned) {
+            // the bounce slot's previous slice must have left for the device
+            if (k >= kSlots) ue = hipEventSynchronize(ctx->bounce_ev[slot]);
+            if (ue != hipSuccess) return ue;
+            segs.clear();
+            add_segs(segs, bounce_slot(ctx, slot), src, b1 - b0);
+            CopyPool::get().run(segs.data(), segs.size());
+            src = bounce_slot(ctx, slot);
+        }
+        // the slot's previous slice must have been validated
+        if (k >= kSlots) ue = hipStreamWaitEvent(cs, ctx->ring_free[slot], 0);
+        if (ue == hipSuccess)
+            ue = hipMemcpyAsync(slot_base(ctx, slot, b0) + b0, src, b1 - b0, hipMemcpyHostToDevice, cs);
+        if (ue == hipSuccess && !pinned) ue = hipEventRecord(ctx->bounce_ev[slot], cs);
+        if (ue == hipSuccess) ue = hipEventRecord(ctx->ring_ready[slot], cs);
+        return ue;
+    };
+    uint32_t uploaded = 0;
+    for (; uploaded < n_slices && uploaded < kSlots && e == hipSuccess; ++uploaded) e = upload(uploaded);
+    oval_layout* l = nullptr;
+    int rc = e == hipSuccess ? host_layout_for(ctx, descs, n_obj, body_host, body_bytes, &l) : OVAL_OK;
+    if (rc || (l && l->span_bytes != span)) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->copy_stream2);
+        return rc ? rc : fail(OVAL_E_LAYOUT, "descriptor table does not end where its last entry does");
+    }
     if (e == hipSuccess && (n_obj > ctx->host_res_cap || !ctx->host_res_dev)) {
         if (ctx->host_res_dev) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->host_res_dev); }
         ctx->host_res_dev = nullptr; ctx->host_res_cap = 0;
@@ -951,39 +1012,20 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
     oval_obj_result* const res_dev = ctx->host_res_dev;
     unsigned long long* const cnt_dev = ctx->host_cnt_dev;
     if (e == hipSuccess) e = hipMemsetAsync(cnt_dev, 0, OVAL_NUM_COUNTERS * 8, ctx->stream);
-    const uint32_t n_tiles = tiles_of(l);
-    const oval::LayoutView v = view_of(l);
-    if (e == hipSuccess) e = oval::launch_init_results(ctx->stream, v, res_dev, cnt_dev);
-    constexpr uint32_t kSlots = oval_ctx::kRingSlots;
-    std::vector<CopySeg> segs;
-    uint32_t k = 0;
-    for (uint32_t t0 = 0; t0 < n_tiles && e == hipSuccess; t0 += kSliceTiles, ++k) {
-        const uint32_t t1 = t0 + kSliceTiles < n_tiles ? t0 + kSliceTiles : n_tiles;
-        const uint32_t slot = k % kSlots;
-        const uint64_t b0 = (uint64_t)t0 * kTileBytes;
-        uint64_t b1 = (uint64_t)t1 * kTileBytes;
-        if (b1 > l->span_bytes) b1 = l->span_bytes;
-        const char* src = (const char*)body_host + b0;
-        if (!pinned && b1 > b0) {
-            // the bounce slot's previous slice must have left for the device
-            if (k >= kSlots) e = hipEventSynchronize(ctx->bounce_ev[slot]);
-            if (e != hipSuccess) break;
-            segs.clear();
-            add_segs(segs, bounce_slot(ctx, slot), src, b1 - b0);
-            CopyPool::get().run(segs.data(), segs.size());
-            src = bounce_slot(ctx, slot);
+    if (e == hipSuccess) {
+        const oval::LayoutView v = view_of(l);
+        e = oval::launch_init_results(ctx->stream, v, res_dev, cnt_dev);
+        for (uint32_t k = 0; k < n_slices && e == hipSuccess; ++k) {
+            if (k >= uploaded) { e = upload(k); ++uploaded; }
+            const uint32_t slot = k % kSlots;
+            const uint32_t t0 = k * kSliceTiles;
+            const uint32_t t1 = t0 + kSliceTiles < l->n_tiles ? t0 + kSliceTiles : l->n_tiles;
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ring_ready[slot], 0);
+            if (e == hipSuccess)
+                e = oval::launch_validate(ctx->stream, cfg_of(ctx), v, slot_base(ctx, slot, (uint64_t)k * kSliceBytes), t0, t1,
+                                          res_dev, cnt_dev, ctx->tallies_dev);
+            if (e == hipSuccess) e = hipEventRecord(ctx->ring_free[slot], ctx->stream);
         }
-        // the slot's previous slice must have been validated
-        if (k >= kSlots) e = hipStreamWaitEvent(ctx->copy_stream, ctx->ring_free[slot], 0);
-        if (e == hipSuccess && b1 > b0)
-            e = hipMemcpyAsync(slot_base(ctx, slot, b0) + b0, src, b1 - b0, hipMemcpyHostToDevice, ctx->copy_stream);
-        if (e == hipSuccess && !pinned) e = hipEventRecord(ctx->bounce_ev[slot], ctx->copy_stream);
-        if (e == hipSuccess) e = hipEventRecord(ctx->ring_ready[slot], ctx->copy_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ring_ready[slot], 0);
-        if (e == hipSuccess)
-            e = oval::launch_validate(ctx->stream, cfg_of(ctx), v, slot_base(ctx, slot, b0), t0, t1, res_dev, cnt_dev,
-                                      ctx->tallies_dev);
-        if (e == hipSuccess) e = hipEventRecord(ctx->ring_free[slot], ctx->stream);
     }
     if (e == hipSuccess && n_obj)
         e = hipMemcpyAsync(results_host, res_dev, n_obj * sizeof(oval_obj_result), hipMemcpyDeviceToHost, ctx->stream);
@@ -991,7 +1033,8 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
         e = hipMemcpyAsync(counters_host, cnt_dev, OVAL_NUM_COUNTERS * 8, hipMemcpyDeviceToHost, ctx->stream);
     const hipError_t e1 = hipStreamSynchronize(ctx->stream);
     const hipError_t e2 = hipStreamSynchronize(ctx->copy_stream);
-    if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+    const hipError_t e3 = hipStreamSynchronize(ctx->copy_stream2);
+    if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "validate_batch_host: %s", hipGetErrorString(e));
     return OVAL_OK;
 }

@@ -819,13 +819,13 @@ namespace {
 // the last one is in.
 bool parts_advance(Parts* p, uint32_t upto)
 {
-    if (upto > p->landed_upto) {
-        const hipError_t e = hipEventSynchronize(p->landed[upto - 1]);   // the copy stream completes them in order
+    while (p->landed_upto < upto) {                          // slices may land out of order: every one is waited for
+        const hipError_t e = hipEventSynchronize(p->landed[p->landed_upto]);
         if (e != hipSuccess) {
             p->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e);
             return false;
         }
-        p->landed_upto = upto;
+        p->landed_upto++;
     }
     if (p->s && p->landed_upto == p->landed.size()) {
         release_slot(p->s);
