@@ -4,9 +4,12 @@
 One step = one fill pass + one validate pass over one resident batch of
 synthetic objects (default: 1,000,000 objects of 4k-16k per GPU, sizes by
 DecideSize, pinned unix time), followed for N > 1 by the single all-reduce of
-the counter vector.  Objects shard by worker key range: rank r owns the key
-space of process ID r (64 workers), so no body byte crosses GPUs and scaling
-is weak.  Prints ONE JSON line on rank 0.
+the counter vector.  Objects shard by worker key range (--sharding workers, the
+default): ONE key space, process ID 0, of N x the per-GPU workers and objects
+(internal/runner/runner.go:117-124), cut into contiguous worker ranges, one per
+rank; --sharding process gives rank r the whole key space of process ID r
+instead (the reference's multi-process mode).  Either way no body byte crosses
+GPUs and scaling is weak.  Prints ONE JSON line on rank 0.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -35,40 +38,92 @@ WORKLOADS = {
 }
 
 
-def build_batch(name, rank, n_obj_override, seed, size_override=None):
-    from oval_amd.batch import WorkerSpace, synthetic_batch
+def build_batch(name, rank, world, sharding, n_obj_override, seed, size_override=None):
+    """This rank's descriptors and a description of how the key space was cut."""
+    from oval_amd.batch import WorkerSpace, shard_workers, synthetic_batch
 
     n_obj, n_worker, lo, hi, _ = WORKLOADS[name]
     if n_obj_override:
         n_obj = n_obj_override
     if size_override:
         lo, hi = size_override
-    n_worker = min(n_worker, n_obj)
-    n_obj -= n_obj % n_worker
-    space = WorkerSpace(num_obj=n_obj, num_worker=n_worker, runner_id=rank, start_worker_id=0x561B)
-    return synthetic_batch(space, range(n_worker), "test-bucket", lo, hi, seed=seed, unix_micro=T0)
+    if sharding == "process":
+        n_worker = min(n_worker, n_obj)
+        n_obj -= n_obj % n_worker
+        space = WorkerSpace(num_obj=n_obj, num_worker=n_worker, runner_id=rank, start_worker_id=0x561B)
+        mine = range(n_worker)
+        how = f"process ID = rank, {n_worker} workers x {space.per_worker} objects each"
+    else:
+        # one key space for the whole job: per-GPU workers x N workers (num_worker < 256,
+        # cmd/root.go:170-173), per-GPU objects x N objects, rank r owns a contiguous worker range
+        per_gpu_workers = max(1, min(n_worker, 255 // world, n_obj))
+        n_obj -= n_obj % per_gpu_workers
+        space = WorkerSpace(num_obj=n_obj * world, num_worker=per_gpu_workers * world, runner_id=0,
+                            start_worker_id=0x561B)
+        mine = shard_workers(space.num_worker, world, rank)
+        how = (f"one key space (process ID 0): {space.num_worker} workers x {space.per_worker} objects = "
+               f"{space.num_obj} objects, contiguous worker ranges per rank (rank 0: workers {mine.start}-{mine.stop - 1})")
+    return synthetic_batch(space, mine, "test-bucket", lo, hi, seed=seed, unix_micro=T0), how
 
 
-def cpu_baseline(descs, budget_s, threads):
-    """The oracle (a C port of the reference's pattern.go) on this host's cores,
-    over a bounded prefix of the same batch: fill then validate, per slice."""
+def host_cpu_share():
+    """Threads a CPU-bound pool may use here: the CPUs this process may run on,
+    cut to the container's declared share where there is one (a cgroup CPU quota,
+    or the pool size the environment sets for OpenMP)."""
+    info = {"os_cpu_count": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0))}
+    share = info["affinity_cpus"]
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            info["cgroup_cpu_quota"] = round(int(quota) / int(period), 2)
+            share = min(share, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    omp = os.environ.get("OMP_NUM_THREADS", "")
+    if omp.isdigit() and int(omp) > 0:
+        info["omp_num_threads"] = int(omp)
+        share = min(share, int(omp))
+    info["threads_used"] = max(1, share)
+    return info
+
+
+def go_toolchain():
+    """`go version` if a Go toolchain is on this box (the reference is Go)."""
+    import shutil
+    import subprocess
+
+    exe = shutil.which("go")
+    if not exe:
+        return "absent (no `go` on PATH): the reference's own pattern package cannot be timed here"
+    try:
+        return subprocess.run([exe, "version"], capture_output=True, text=True, timeout=20).stdout.strip()
+    except Exception as e:  # noqa: BLE001
+        return f"present but `go version` failed: {e}"
+
+
+def _cpu_run(descs, budget_s, threads, variant):
+    """One timing of the oracle over a bounded prefix of the batch, `threads`
+    object streams side by side (one goroutine per worker in the reference,
+    internal/runner/runner.go:186-214).  Returns (GB/s, objects, units, seconds)."""
     from oracle import oracle as O
     from oval_amd.batch import span_bytes
 
-    O.build()
     D = descs.view(O.DESC_DTYPE)
-    slice_objs = max(1, min(len(descs), 20000))
+    slice_objs = max(1, min(len(descs), 20000 if variant == "port" else 5000))
 
     def run_slice(lo, out):
         d = D[lo:lo + slice_objs].copy()
         d["body_offset"] -= d["body_offset"][0]
-        body = np.empty(span_bytes(d), dtype=np.uint8)
-        t = time.perf_counter()
-        O.fill_batch(d, body)
-        res, _ = O.validate_batch(d, body)
-        dt = time.perf_counter() - t
-        assert (res["first_bad_unit"] == O.NO_BAD).all()
-        out.append((int(d["n_units"].sum()), dt))
+        if variant == "port":
+            body = np.empty(span_bytes(d), dtype=np.uint8)
+            O.fill_batch(d, body)
+            res, _ = O.validate_batch(d, body)
+            assert (res["first_bad_unit"] == O.NO_BAD).all()
+            out.append(int(d["n_units"].sum()))
+        else:
+            units, bad = O.refshape_generate_valid(d)
+            assert bad == 0
+            out.append(units)
 
     done, t_start, lo = [], time.perf_counter(), 0
     while lo < len(descs) and time.perf_counter() - t_start < budget_s:
@@ -85,11 +140,39 @@ def cpu_baseline(descs, budget_s, threads):
             th.join()
         done += [o[0] for o in outs]
     wall = time.perf_counter() - t_start
-    units = sum(u for u, _ in done)
+    units = sum(done)
+    return 512.0 * units / wall / 1e9, min(lo, len(descs)), units, wall
+
+
+def cpu_baseline(descs, budget_s):
+    """The oracle (a C restatement of the reference's pattern.go) on this host's
+    cores over a bounded prefix of the same batch, generate then validate, in two
+    variants: the plain port (template copy per unit) and one shaped like the
+    reference's code (per unit: formatted print, small allocations, a clock read,
+    append copies; pattern.go:95-115), each on one thread and on the host's share
+    of cores.  `value` is the faster one (the port) on all of them."""
+    from oracle import oracle as O
+
+    O.build()
+    share = host_cpu_share()
+    n = share["threads_used"]
+    port_all = _cpu_run(descs, budget_s / 4, n, "port")
+    port_one = _cpu_run(descs, budget_s / 4, 1, "port")
+    ref_all = _cpu_run(descs, budget_s / 4, n, "refshape")
+    ref_one = _cpu_run(descs, budget_s / 4, 1, "refshape")
     return {
-        "value": round(512.0 * units / wall / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
-        "sample": f"oracle fill+validate of the first {min(lo, len(descs))} objects ({units} units, "
-                  f"{units * 256 / 1e9:.2f} GB) of the same batch, {wall:.1f} s, {threads} thread(s)",
+        "value": round(port_all[0], 4), "unit": "GB/s", "cores": n, "kind": "port",
+        "sample": f"oracle generate+validate of the first {port_all[1]} objects ({port_all[2]} units, "
+                  f"{port_all[2] * 256 / 1e9:.2f} GB) of the same batch, {port_all[3]:.1f} s, {n} thread(s)",
+        "single_thread_value": round(port_one[0], 4),
+        "reference_shaped": {
+            "value": round(ref_all[0], 4), "single_thread_value": round(ref_one[0], 4), "cores": n,
+            "sample": f"first {ref_all[1]} objects ({ref_all[2]} units), {ref_all[3]:.1f} s; per unit: printf-formatted "
+                      "names, 4 small allocations, clock_gettime, 52 four-byte appends, 256-byte append copy, "
+                      "256-byte read + 2 string copies + TrimSpace compare (pattern.go:95-115,124-170)",
+        },
+        "host": share,
+        "go_toolchain": go_toolchain(),
     }
 
 
@@ -102,7 +185,16 @@ def main():
     ap.add_argument("--objects", type=int, default=0, help="objects per GPU (default: the workload's)")
     ap.add_argument("--fill-threads", type=int, default=0, help="workgroup size of the fill kernel (0 = default)")
     ap.add_argument("--validate-threads", type=int, default=0, help="workgroup size of the validate kernel")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--corrupt", type=float, default=0.0,
+                    help="fraction of units damaged after every fill (half bit flips, half stale generations; "
+                         "seeded per rank): the cfg4 / cfg5 shape.  The injection is inside the step, so `value` "
+                         "is not the headline figure then")
+    ap.add_argument("--verify-oracle", action="store_true",
+                    help="rank 0 recomputes every rank's shard with the CPU oracle and requires the all-reduced "
+                         "counters to equal the oracle's over the whole batch (small --objects only)")
+    ap.add_argument("--sharding", default="workers", choices=["workers", "process"],
+                    help="workers: one key space cut into worker ranges (default); process: rank r = process ID r")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--collective", default="torch", choices=["torch", "capi"],
                     help="who runs the counter all-reduce: torch.distributed (default) or the library's own "
@@ -123,7 +215,7 @@ def main():
     import torch
 
     from oval_amd import engine
-    from oval_amd.batch import span_bytes, split_batches
+    from oval_amd.batch import DeviceCorruption, plan_corruption, span_bytes, split_batches
     from oval_amd.dist import all_reduce, all_reduce_counters
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +227,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the pattern engine has no CPU path")
     if args.backend != "nccl":
         local %= torch.cuda.device_count()
+    elif world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {world} over RCCL needs {world} visible GPUs, this node shows "
+                         f"{torch.cuda.device_count()}: one rank per GPU (use --backend gloo to rehearse more "
+                         "ranks than GPUs)")
+    if args.collective == "capi" and world > torch.cuda.device_count():
+        raise SystemExit(f"--collective capi runs RCCL in the library and needs one GPU per rank: {world} ranks, "
+                         f"{torch.cuda.device_count()} visible GPUs")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -159,7 +258,7 @@ def main():
         comm = engine.Comm(ctx, world, rank, uid[0])
 
     size_override = tuple(int(x) for x in args.sizes.split("-")) if args.sizes else None
-    descs = build_batch(args.workload, rank, args.objects, args.seed, size_override)
+    descs, sharding_how = build_batch(args.workload, rank, world, args.sharding, args.objects, args.seed, size_override)
     n_obj, units = len(descs), int(descs["n_units"].sum())
     # One resident layout per sub-batch (descriptors + chunk table stay on the
     # device), one body buffer reused by all of them.
@@ -169,6 +268,11 @@ def main():
     body = torch.empty(max(span_bytes(p) for p in parts), dtype=torch.uint8, device=f"cuda:{local}")
     results = [torch.empty((len(p), 4), dtype=torch.int32, device=body.device) for p in parts]
     counters = torch.zeros(engine.NUM_COUNTERS, dtype=torch.int64, device=body.device)
+    damage = None
+    if args.corrupt > 0:
+        # sub-batch k of rank r is damaged with seed (seed, r, k): reproducible on any other rank
+        damage = [DeviceCorruption(p, plan_corruption(p, args.corrupt, seed=args.seed * 1000003 + rank * 1009 + k),
+                                   body.device) for k, p in enumerate(parts)]
 
     def step(timers=None):
         counters.zero_()
@@ -177,6 +281,7 @@ def main():
             if tf: tf.start()
             layout.fill(body)
             if tf: tf.stop()
+            if damage: damage[k].apply(body)
             if tv: tv.start()
             layout.validate(body, results[k], counters)
             if tv: tv.stop()
@@ -210,9 +315,27 @@ def main():
         wall, units_all = float(mx[0]), float(sm[1])
     else:
         units_all = float(units)
-    # the batch was clean: nothing may be reported bad, everything must have been checked
-    assert int(tot[1]) == 0 and int(tot[3]) == 0, f"clean batch reported corrupt: {tot}"
+    # everything must have been checked; a clean batch may report nothing bad
     assert int(tot[2]) == int(units_all), (int(tot[2]), units_all)
+    if not damage:
+        assert int(tot[1]) == 0 and int(tot[3]) == 0, f"clean batch reported corrupt: {tot}"
+    verified = None
+    if args.verify_oracle and rank == 0:
+        # the whole job on the CPU: every rank's shard, its damage, the oracle's counters summed
+        from oracle import oracle as O
+        from oval_amd.batch import apply_corruption_numpy
+
+        expect = np.zeros(engine.NUM_COUNTERS, dtype=np.uint64)
+        for r in range(world):
+            d_r, _ = build_batch(args.workload, r, world, args.sharding, args.objects, args.seed, size_override)
+            for k, p in enumerate(split_batches(d_r, int(args.batch_gib * (1 << 30)))):
+                host = np.zeros(span_bytes(p), dtype=np.uint8)
+                O.fill_batch(p.view(O.DESC_DTYPE), host)
+                if args.corrupt > 0:
+                    apply_corruption_numpy(host, p, plan_corruption(p, args.corrupt, seed=args.seed * 1000003 + r * 1009 + k))
+                expect += O.validate_batch(p.view(O.DESC_DTYPE), host)[1]
+        assert np.array_equal(tot.astype(np.uint64), expect), f"counters {tot} differ from the oracle's {expect}"
+        verified = [int(x) for x in expect]
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
@@ -228,14 +351,18 @@ def main():
         n_val = sum(l.launches()[1] for l in layouts)
         dom, dom_ms, dom_gbs, dom_n = ((val_name, val_ms, val_gbs, n_val) if val_ms >= fill_ms
                                        else (fill_name, fill_ms, fill_gbs, n_fill))
-        traffic = None
+        traffic, traffic_source = None, "none: no stored PMC pass for this shape"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 if not (args.objects or args.sizes):             # measured on the default shape only
                     # the file holds HBM bytes per pass over the batch (PMC passes); per launch here
-                    per_pass = json.load(open(tpath)).get(args.workload, {}).get(dom)
+                    stored = json.load(open(tpath))
+                    per_pass = stored.get(args.workload, {}).get(dom)
                     traffic = per_pass // max(dom_n, 1) if per_pass else None
+                    if traffic:
+                        traffic_source = ("profiles/traffic.json: " + stored.get("source", "an earlier rocprofv3 --pmc pass")
+                                          + "; NOT measured in this run")
             except Exception:
                 traffic = None
         out = {
@@ -244,11 +371,12 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload][4]}", "objects_per_gpu": n_obj,
-                       "units_per_gpu": units, "bytes_per_gpu": nbytes, "sub_batches": len(parts), "sharding": "worker key range (process ID = rank)", "collective": args.collective,
+                       "units_per_gpu": units, "bytes_per_gpu": nbytes, "sub_batches": len(parts), "sharding": sharding_how, "collective": args.collective,
                        "fill_threads": args.fill_threads or 256, "validate_threads": args.validate_threads or 256},
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBS, 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(dom_gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(dom_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          # a pass over the batch is `launches_per_step` equal launches of this kernel; the
                          # HIP events bracket the pass, small helper kernels and launch gaps included
                          "launches_per_step": dom_n, "algorithmic_bytes_per_launch": 256 * units // max(dom_n, 1),
@@ -257,12 +385,13 @@ def main():
                         "validate_ms": round(val_ms, 4), "validate_GBps": round(val_gbs, 1),
                         "fill_launches": n_fill, "validate_launches": n_val},
         }
+        if damage:
+            out["config"]["corrupt_fraction"] = args.corrupt
+            out["counters"] = [int(x) for x in tot]
+        if verified is not None:
+            out["counters_equal_oracle"] = True
         if world == 1 and args.cpu_seconds > 0:
-            # all of this process's share of the host cores, and one core beside it
-            cores = max(1, min(16, len(os.sched_getaffinity(0))))
-            out["cpu_baseline"] = cpu_baseline(descs, args.cpu_seconds / 2, cores)
-            one = cpu_baseline(descs, args.cpu_seconds / 2, 1)
-            out["cpu_baseline"]["single_thread_value"] = one["value"]
+            out["cpu_baseline"] = cpu_baseline(descs, args.cpu_seconds)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm:
         torch.cuda.synchronize()

@@ -106,6 +106,8 @@ def lib():
         L.oracle_validate_batch.restype = None
         L.oracle_validate_batch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
                                             C.c_void_p, C.c_void_p]
+        L.oracle_refshape_generate_valid.restype = C.c_uint64
+        L.oracle_refshape_generate_valid.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         _ = u8p
         _lib = L
     return _lib
@@ -244,3 +246,12 @@ def validate_batch(descs: np.ndarray, body: np.ndarray):
     lib().oracle_validate_batch(descs.ctypes.data, len(descs), body.ctypes.data, body.size,
                                 res.ctypes.data, counters.ctypes.data)
     return res, counters
+
+
+def refshape_generate_valid(descs: np.ndarray):
+    """Timing variant shaped like pattern.go's per-unit work (CPU baseline only):
+    Generate then Valid of every object.  Returns (units, bad units)."""
+    assert descs.dtype == DESC_DTYPE and descs.flags.c_contiguous
+    bad = C.c_uint64()
+    units = lib().oracle_refshape_generate_valid(descs.ctypes.data, len(descs), C.byref(bad))
+    return int(units), int(bad.value)

@@ -6,12 +6,14 @@
  * append-copy structure, so that it doubles as the "port" CPU baseline.
  * Build with -ffp-contract=off (decide_size must not fuse multiply-adds).
  */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime */
 #include "oval_oracle.h"
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------------ */
 /* unicode/utf8 (Go standard library; not part of the reference tree)        */
@@ -609,4 +611,95 @@ void oracle_validate_batch(const oracle_desc* d, uint64_t n_obj,
     }
     if (counters)
         for (int i = 0; i < ORACLE_NUM_COUNTERS; i++) counters[i] += c[i];
+}
+
+/* ------------------------------------------------------------------------ */
+/* timing variant shaped like the reference's code                           */
+/* ------------------------------------------------------------------------ */
+/* For the CPU baseline only: Generate then Valid of every object of the table,
+ * paying per unit what pattern.go pays per unit -- the format string rebuilt
+ * and the names formatted through a printf (pattern.go:95,98), two string to
+ * []byte conversions and two buffers allocated (:97-100), the clock read
+ * (:103), 52 four-byte appends (:109-114), the unit appended to the object's
+ * buffer (:84); and on the way back a 256-byte read into a buffer (:124), two
+ * []byte to string conversions (:139,146), TrimSpace and the compares
+ * (:140-170).  The time stamp is the wall clock, so its bytes differ from a
+ * table's pinned time; nothing validates them.  Returns the number of units
+ * generated and validated; *bad_out counts units that did not validate (0 for
+ * a correct run). */
+static uint8_t* refshape_unit(int64_t unit_count, int64_t worker_id, const char* bucket, const char* key,
+                              int64_t write_count, size_t* len_out)
+{
+    char format[32];
+    snprintf(format, sizeof format, "%%-%ds%%-%ds", ORACLE_MAX_BUCKET, ORACLE_MAX_KEY);   /* :95 */
+    int64_t offset_in_object = unit_count * ORACLE_UNIT_SIZE;                              /* :96 */
+    uint8_t* data = (uint8_t*)malloc(ORACLE_UNIT_SIZE);                                    /* :97 */
+    size_t len = 0;
+    char* header = (char*)malloc(ORACLE_MAX_BUCKET + ORACLE_MAX_KEY + 64);                 /* Sprintf's string */
+    int hl = snprintf(header, ORACLE_MAX_BUCKET + ORACLE_MAX_KEY + 64, format, bucket, key);
+    uint8_t* hbytes = (uint8_t*)malloc((size_t)hl + 1);                                    /* []byte(string) */
+    memcpy(hbytes, header, (size_t)hl);
+    memcpy(data + len, hbytes, (size_t)hl);                                                /* :98 append */
+    len += (size_t)hl;
+    uint8_t* num = (uint8_t*)malloc(ORACLE_HDR_NUM);                                       /* :100 */
+    put_u32le(num + 0, (uint32_t)write_count);
+    put_u32le(num + 4, (uint32_t)offset_in_object);
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);                                                    /* :103 time.Now() */
+    uint64_t micro = (uint64_t)ts.tv_sec * 1000000ull + (uint64_t)ts.tv_nsec / 1000ull;
+    put_u32le(num + 8, (uint32_t)worker_id);
+    put_u64le(num + 12, micro);
+    memcpy(data + len, num, ORACLE_HDR_NUM);                                               /* :107 */
+    len += ORACLE_HDR_NUM;
+    for (int i = ORACLE_MAX_BUCKET + ORACLE_MAX_KEY + ORACLE_HDR_NUM; i < ORACLE_UNIT_SIZE; i += 4) {
+        uint8_t four[4] = {(uint8_t)i, (uint8_t)(i + 1), (uint8_t)(i + 2), (uint8_t)(i + 3)};
+        memcpy(data + len, four, 4);                                                       /* :113 append */
+        len += 4;
+    }
+    free(num);
+    free(hbytes);
+    free(header);
+    *len_out = len;
+    return data;
+}
+
+uint64_t oracle_refshape_generate_valid(const oracle_desc* d, uint64_t n_obj, uint64_t* bad_out)
+{
+    uint64_t units = 0, bad = 0;
+    for (uint64_t o = 0; o < n_obj; o++) {
+        const oracle_desc* e = &d[o];
+        char bucket[ORACLE_MAX_BUCKET + 1], key[ORACLE_MAX_KEY + 1];
+        memcpy(bucket, e->bucket, e->bucket_len); bucket[e->bucket_len] = 0;
+        memcpy(key, e->key, e->key_len); key[e->key_len] = 0;
+        /* Generate, pattern.go:73-92 */
+        size_t data_size = (size_t)e->n_units * ORACLE_UNIT_SIZE, len = 0;
+        uint8_t* data = (uint8_t*)malloc(data_size ? data_size : 1);                       /* :78 */
+        for (uint32_t u = 0; u < e->n_units; u++) {
+            size_t ulen = 0;
+            uint8_t* unit = refshape_unit((int64_t)e->first_unit + u, (int64_t)e->worker_id, bucket, key,
+                                          (int64_t)e->write_count, &ulen);
+            if (len + ulen <= data_size) memcpy(data + len, unit, ulen);                   /* :84 append */
+            len += ulen;
+            free(unit);
+        }
+        if (len != data_size) bad += e->n_units;                                           /* :87-89 */
+        /* Valid, pattern.go:118-134 over a reader on those bytes */
+        uint8_t buf[ORACLE_UNIT_SIZE];                                                     /* :122 */
+        for (uint32_t u = 0; u < e->n_units && len == data_size; u++) {
+            memcpy(buf, data + (size_t)u * ORACLE_UNIT_SIZE, ORACLE_UNIT_SIZE);            /* :124 io.ReadFull */
+            char* s1 = (char*)malloc(ORACLE_MAX_BUCKET);                                   /* :139 string(data[0:16]) */
+            memcpy(s1, buf, ORACLE_MAX_BUCKET);
+            char* s2 = (char*)malloc(ORACLE_MAX_KEY);                                      /* :146 */
+            memcpy(s2, buf + ORACLE_MAX_BUCKET, ORACLE_MAX_KEY);
+            int m = oracle_valid_unit((int64_t)e->first_unit + u, (int64_t)e->worker_id, e->bucket, e->bucket_len,
+                                      e->key, e->key_len, (int64_t)e->write_count, buf, NULL, 0);
+            if (m) bad++;
+            free(s2);
+            free(s1);
+        }
+        units += e->n_units;
+        free(data);
+    }
+    if (bad_out) *bad_out = bad;
+    return units;
 }

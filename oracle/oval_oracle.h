@@ -110,6 +110,12 @@ void oracle_validate_batch(const oracle_desc* d, uint64_t n_obj,
                            const uint8_t* body, uint64_t body_bytes,
                            oracle_result* res, uint64_t* counters);
 
+/* CPU-baseline timing variant: Generate then Valid of every object, paying per
+ * unit what pattern.go:94-116 and :118-180 pay per unit (printf formatting,
+ * small allocations, a clock read, append copies).  Returns units processed;
+ * *bad_out = units that failed to validate (0 for a correct run). */
+uint64_t oracle_refshape_generate_valid(const oracle_desc* d, uint64_t n_obj, uint64_t* bad_out);
+
 #ifdef __cplusplus
 }
 #endif

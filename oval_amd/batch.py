@@ -267,3 +267,26 @@ def apply_corruption_torch(body, descs: np.ndarray, plan: CorruptionPlan) -> Non
         np.bitwise_xor.at(m, inv, plan.flip_mask)
         idx = torch.from_numpy(ub.astype(np.int64)).to(dev)
         body[idx] = body[idx] ^ torch.from_numpy(m).to(dev)
+
+
+class DeviceCorruption:
+    """A corruption plan resident on the device, for loops that re-apply it after
+    every fill (benchmarks of the cfg4 / cfg5 shape)."""
+
+    def __init__(self, descs: np.ndarray, plan: CorruptionPlan, device):
+        import torch
+
+        offs, vals = stale_patches(descs, plan)
+        self.offs = torch.from_numpy(offs).to(device)
+        self.vals = torch.from_numpy(vals).to(device)
+        ub, inv = np.unique(plan.flip_byte, return_inverse=True)
+        m = np.zeros(len(ub), dtype=np.uint8)
+        np.bitwise_xor.at(m, inv, plan.flip_mask)          # a byte may be hit twice
+        self.flip_idx = torch.from_numpy(ub.astype(np.int64)).to(device)
+        self.flip_mask = torch.from_numpy(m).to(device)
+
+    def apply(self, body) -> None:
+        if self.offs.numel():
+            body[self.offs] = self.vals
+        if self.flip_idx.numel():
+            body[self.flip_idx] = body[self.flip_idx] ^ self.flip_mask

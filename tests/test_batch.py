@@ -118,3 +118,30 @@ def test_split_batches_rebases_and_covers():
     assert split_batches(d[:0], 100) == []
     with pytest.raises(ValueError):
         split_batches(d, 0)
+
+
+def test_bench_shards_one_key_space_by_worker_range():
+    """bench.py --sharding workers: the ranks' batches are disjoint worker ranges
+    of ONE key space (process ID 0) and together cover it (runner.go:117-124)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    world = 8
+    shards = [bench.build_batch("cfg5", r, world, "workers", 2480, 1)[0] for r in range(world)]
+    keys = np.concatenate([s["key"] for s in shards])
+    assert len(np.unique(keys, axis=0)) == len(keys) == 8 * 2480 - (8 * 2480) % 248
+    texts = [bytes(k).decode() for k in keys]
+    assert all(t.startswith("ov00") for t in texts)                      # process ID 0 everywhere
+    workers = sorted({int(t[4:6], 16) for t in texts})
+    assert workers == list(range(248))                                   # 31 workers per rank, 248 < 256
+    for r, s in enumerate(shards):
+        w = {int(bytes(k).decode()[4:6], 16) for k in s["key"]}
+        assert w == set(range(31 * r, 31 * r + 31))
+    # the same objects whatever the world size: a worker's stream does not depend on the cut
+    one = bench.build_batch("cfg5", 0, 1, "workers", 0, 1)[1]
+    assert "one key space" in one
+    by_process = [bench.build_batch("cfg2", r, 2, "process", 640, 1)[0] for r in range(2)]
+    assert bytes(by_process[1]["key"][0]).decode().startswith("ov01")     # process ID = rank

@@ -33,6 +33,10 @@ def test_single_rank_line():
     assert d["roofline"]["peak"] == 8000.0 and d["roofline"]["launches_per_step"] >= 1
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and "model" not in d["config"]
+    cb = d["cpu_baseline"]
+    assert cb["reference_shaped"]["value"] > 0 and cb["host"]["threads_used"] == cb["cores"] >= 1
+    assert "go_toolchain" in cb and cb["host"]["os_cpu_count"] >= cb["host"]["threads_used"]
+    assert "traffic_source" in d["roofline"]
 
 
 def test_two_rank_rehearsal_sums_units_over_ranks():
@@ -43,3 +47,30 @@ def test_two_rank_rehearsal_sums_units_over_ranks():
     # whole-job value: both ranks' units over the slowest rank's time
     per_gpu = d["config"]["units_per_gpu"]
     assert abs(d["value"] - 512.0 * 2 * per_gpu / (d["ms_per_step"] / 1e3) / 1e9) / d["value"] < 0.05
+
+
+@pytest.mark.parametrize("sharding", ["workers", "process"])
+def test_two_rank_rehearsal_with_damage_counters_equal_the_oracle(sharding):
+    """cfg5's shape in small: two ranks, each damages its own shard (seeded per
+    rank), one all-reduce of the 12 counters; rank 0 recomputes the WHOLE batch
+    with the CPU oracle and requires every counter to match."""
+    port = "29543" if sharding == "workers" else "29545"
+    d = _one_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                   "--master-addr", "127.0.0.1", "--master-port", port, "bench.py", "--gpus", "2",
+                   "--backend", "gloo", "--objects", "30000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+                   "--workload", "cfg5", "--sizes", "4096-262144", "--corrupt", "1e-4", "--verify-oracle",
+                   "--sharding", sharding])
+    assert d["counters_equal_oracle"] is True
+    c = d["counters"]
+    assert c[0] == 2 * d["config"]["objects_per_gpu"] and c[1] > 0 and c[3] >= c[1] and c[9] >= c[3]
+    if sharding == "workers":
+        assert "one key space (process ID 0)" in d["config"]["sharding"]
+
+
+def test_capi_collective_refuses_more_ranks_than_gpus():
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", "bench.py", "--gpus", "2",
+                        "--backend", "gloo", "--collective", "capi", "--objects", "2000", "--steps", "1",
+                        "--warmup", "0", "--cpu-seconds", "0"], cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert p.returncode != 0
+    assert "needs one GPU per rank" in p.stderr
