@@ -7,7 +7,9 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GO_FILE = os.path.join(ROOT, "go", "internal", "pattern", "pattern_hip.go")
+GO_DIR = os.path.join(ROOT, "go", "internal", "pattern")
+GO_FILE = os.path.join(GO_DIR, "pattern_hip.go")
+GO_FILES = sorted(os.path.join(GO_DIR, f) for f in os.listdir(GO_DIR) if f.endswith(".go"))
 
 
 def _strip_c_comments(text):
@@ -60,11 +62,15 @@ def _go_calls(src):
 
 
 def test_every_c_call_matches_a_declaration():
-    src = open(GO_FILE).read()
-    go_code = re.sub(r"//[^\n]*", "", src.split('import "C"', 1)[1])
+    assert len(GO_FILES) >= 3
+    go_code = ""
+    for f in GO_FILES:
+        src = open(f).read()
+        assert src.startswith("//go:build ovalhip\n"), f
+        go_code += re.sub(r"//[^\n]*", "", src.split('import "C"', 1)[1])
     decls = _declared_functions()
     calls = _go_calls(go_code)
-    assert len(calls) >= 9
+    assert len(calls) >= 16
     types = {"oval_read_fn"}                                   # a conversion, not a call
     for name, n_args in calls:
         if name in types:
@@ -73,7 +79,9 @@ def test_every_c_call_matches_a_declaration():
         assert decls[name] == n_args, f"{name}: Go passes {n_args} arguments, the header declares {decls[name]}"
     used = {n for n, _ in calls}
     for must in ("oval_pattern_generate", "oval_pattern_valid_stream", "oval_pattern_decide_size",
-                 "oval_pattern_generate_data_unit", "oval_pattern_valid_data_unit", "oval_pattern_set_batching"):
+                 "oval_pattern_generate_data_unit", "oval_pattern_valid_data_unit", "oval_pattern_set_batching",
+                 "oval_pattern_generate_parts", "oval_parts_count", "oval_parts_get", "oval_parts_release",
+                 "oval_parts_close", "oval_pattern_generate_batch", "oval_pattern_valid_batch"):
         assert must in used, f"the Go binding does not call {must}"
 
 
@@ -89,8 +97,10 @@ def test_go_file_defines_the_reference_surface_and_has_no_placeholders():
                 r"dataUnitSize\s+= 256"):
         assert re.search(sig, src), sig
     assert "//export ovalGoRead" in src and "size_t ovalGoRead(void* user, uint8_t* p, size_t n);" in src
-    body = src.split('import "C"', 1)[1]
-    assert "/*" not in body and "TODO" not in src and "..." not in body
+    for f in GO_FILES:
+        text = open(f).read()
+        body = text.split('import "C"', 1)[1]
+        assert "/*" not in body and "TODO" not in text and "..." not in body, f
     # the read callback has the type the header gives oval_read_fn
     hdr = _strip_c_comments(open(os.path.join(ROOT, "include", "oval_pattern.h")).read())
     assert re.search(r"typedef\s+size_t\s*\(\*oval_read_fn\)\(void\*\s*user,\s*uint8_t\*\s*p,\s*size_t\s+n\)", hdr)
