@@ -12,7 +12,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from ._lib import DESC_DTYPE, UNIT
+from ._lib import DESC_BUCKET_SLOW, DESC_DTYPE, DESC_KEY_SLOW, DESC_WORKER_OOR, UNIT
 
 _HEX = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)
 MAX_WORKER_ID = 0x10000  # runner.go:22-24
@@ -52,6 +52,14 @@ def pad_name(name: bytes, width: int) -> np.ndarray:
     return np.frombuffer(name + b" " * (width - len(name)), dtype=np.uint8)
 
 
+def _edge_space(field: np.ndarray, lens: np.ndarray) -> np.ndarray:
+    """Per row: the ASCII name of length lens[i] starts or ends with white space."""
+    field = np.asarray(field)
+    first = field[:, 0]
+    last = field[np.arange(len(lens)), np.maximum(lens.astype(np.int64) - 1, 0)]
+    return (lens > 0) & (((first >= 9) & (first <= 13)) | (first == 32) | ((last >= 9) & (last <= 13)) | (last == 32))
+
+
 def build_descs(bucket: str | bytes, keys: np.ndarray, write_counts, worker_ids, unix_micro,
                 sizes_bytes, first_units=0, gap_bytes: int = 0) -> np.ndarray:
     """One descriptor per object; bodies are laid out back to back (plus
@@ -77,8 +85,20 @@ def build_descs(bucket: str | bytes, keys: np.ndarray, write_counts, worker_ids,
     d["bucket_len"] = len(b)
     d["key"] = key_field
     d["key_len"] = key_len
+    if (np.asarray(key_field) >= 0x80).any():
+        raise ValueError("batch tables take ASCII names only")
     d["write_count"] = np.asarray(write_counts, dtype=np.int64).astype(np.uint32)
-    d["worker_id"] = np.asarray(worker_ids, dtype=np.int64).astype(np.uint32)
+    wid = np.asarray(worker_ids, dtype=np.int64)
+    d["worker_id"] = wid.astype(np.uint32)
+    # validDataUnit compares the worker ID as a Go int (pattern.go:166-167): one outside uint32
+    # can never equal what a unit holds, which the descriptor has to say (oval_desc_init does too)
+    d["flags"] = np.where((wid < 0) | (wid > 0xFFFFFFFF), np.uint16(DESC_WORKER_OOR), np.uint16(0))
+    # names with white space at an edge can never equal their trimmed field (pattern.go:140,147);
+    # the library derives these two bits itself, they are set here so that the table also reads right
+    if n:
+        blen = np.full(n, len(b), dtype=np.uint8)
+        d["flags"] |= np.where(_edge_space(np.broadcast_to(pad_name(b, 16), (n, 16)), blen), np.uint16(DESC_BUCKET_SLOW), np.uint16(0))
+        d["flags"] |= np.where(_edge_space(key_field, key_len), np.uint16(DESC_KEY_SLOW), np.uint16(0))
     d["unix_micro"] = np.asarray(unix_micro, dtype=np.uint64)
     d["first_unit"] = np.asarray(first_units, dtype=np.uint32)
     units = (np.asarray(sizes_bytes, dtype=np.int64) // UNIT).astype(np.uint64)

@@ -480,6 +480,10 @@ void put_string(std::string& out, const std::string& s)
             else if (c == '\n') out += "\\n";
             else if (c == '\r') out += "\\r";
             else if (c == '\t') out += "\\t";
+            // encoding/json of Go >= 1.22 (the reference's go.mod says 1.24) writes \b and \f in
+            // their short forms; Go <= 1.21 wrote \u0008 and \u000c.  Readers accept both.
+            else if (c == '\b') out += "\\b";
+            else if (c == '\f') out += "\\f";
             else if (c < 0x20 || c == '<' || c == '>' || c == '&') {
                 out += "\\u00";
                 out.push_back(hex[c >> 4]);

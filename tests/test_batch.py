@@ -145,3 +145,23 @@ def test_bench_shards_one_key_space_by_worker_range():
     assert "one key space" in one
     by_process = [bench.build_batch("cfg2", r, 2, "process", 640, 1)[0] for r in range(2)]
     assert bytes(by_process[1]["key"][0]).decode().startswith("ov01")     # process ID = rank
+
+
+def test_build_descs_flags_what_the_fast_compare_would_miss(oracle):
+    """Names with white space at an edge and worker IDs outside uint32 can never
+    validate in the reference (pattern.go:140,147,166-167): the table says so, as
+    oval_desc_init would, and the oracle reports every unit of such objects."""
+    from oval_amd._lib import DESC_BUCKET_SLOW, DESC_KEY_SLOW, DESC_WORKER_OOR
+    from oval_amd.batch import build_descs
+
+    d = build_descs("b", ["plain", " lead", "trail\t", "ok"], [1, 1, 1, 1], [7, 7, 7, -1], 5, 512)
+    assert list(d["flags"]) == [0, DESC_KEY_SLOW, DESC_KEY_SLOW, DESC_WORKER_OOR]
+    d2 = build_descs(" b", ["k"], [1], [1 << 32], 5, 256)
+    assert d2["flags"][0] == DESC_BUCKET_SLOW | DESC_WORKER_OOR
+    body = np.zeros(int(d["n_units"].sum()) * 256 + 0, dtype=np.uint8)
+    dd = d.copy()
+    oracle.fill_batch(dd.view(oracle.DESC_DTYPE), body)
+    res, cnt = oracle.validate_batch(dd.view(oracle.DESC_DTYPE), body)
+    assert list(res["bad_units"]) == [0, 2, 2, 2]
+    with pytest.raises(ValueError):
+        build_descs("b", np.full((1, 12), 0xC3, dtype=np.uint8), [1], [1], 5, 256)

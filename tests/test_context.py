@@ -98,6 +98,9 @@ def test_marshal_is_go_json():
     # control characters: \n \r \t short forms, the rest \u00XX
     ec2 = X.ExecutionContext.New("a\nb\rc\td\x01e\x7f", ["b"], 1, 1, 256, 256, startWorkerID=0)
     assert b'"endpoint":"a\\nb\\rc\\td\\u0001e\x7f"' in ec2.Marshal()
+    # backspace and form feed in the short forms of Go >= 1.22 (go.mod: go 1.24)
+    ec3 = X.ExecutionContext.New("a\bb\fc", ["b"], 1, 1, 256, 256, startWorkerID=0)
+    assert b'"endpoint":"a\\bb\\fc"' in ec3.Marshal()
 
 
 def test_load_round_trip_and_save_file(tmp_path):
