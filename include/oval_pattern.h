@@ -125,6 +125,11 @@ void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes);
  * on an interrupt (1) or polls (0, default) while its batch is on the device.
  * Values <= 0 / < 0 keep the current setting; applies from the next enable. */
 void oval_pattern_set_lanes(int lanes, int blocking_sync);
+/* Benchmarks only: the callers of a finished batch wake each other through a tree
+ * (the lane wakes `roots` callers, each wakes `fanout` more; defaults 1 and 4), and
+ * a caller may poll for `spin_ns` nanoseconds before it sleeps (default 0).
+ * Negative values keep the current setting. */
+void oval_pattern_set_wake_tuning(int fanout, int roots, int spin_ns);
 void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs);
 
 /* pattern.dump — pattern.go:182-206; and encoding/hex.Dump which feeds it.

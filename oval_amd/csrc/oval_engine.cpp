@@ -74,7 +74,9 @@ void futex_wake(std::atomic<uint32_t>* a, int n)
 // kWakeFanout d + kWakeFanout before it collects its outcome.  One wake-all
 // from the lane thread costs it a few microseconds per sleeper (100+ us for a
 // batch of 100 jobs), during which that lane submits nothing.
-constexpr int kWakeFanout = 4;
+constexpr int kWakeFanout = 4, kWakeRoots = 1;
+std::atomic<int> g_wake_fanout{kWakeFanout}, g_wake_roots{kWakeRoots};   // set_wake_tree(): benchmarks only
+std::atomic<int> g_spin_ns{0};            // how long a caller polls its word before it sleeps on it
 
 uint64_t now_ns()
 {
@@ -125,6 +127,7 @@ struct Slot {
     // a batch do not queue on one kernel futex bucket, and is woken by its parent
     // in a tree over the batch's job numbers (see wake_children).
     std::unique_ptr<WakeWord[]> words;
+    int wake_fanout = kWakeFanout, wake_roots = kWakeRoots;   // shape of the batch's wake tree, fixed when it closes
     bool failed = false;
     std::string err;
 };
@@ -352,10 +355,19 @@ void wake_job(Slot* s, uint32_t d)
     futex_wake(w, 1);
 }
 
+// Job d wakes jobs roots + fanout d ... roots + fanout d + fanout - 1; jobs 0 ... roots - 1 are woken
+// by whoever completed the batch.
 void wake_children(Slot* s, uint32_t d)
 {
     const uint32_t n = s->n_val + s->n_fill;
-    for (uint32_t c = kWakeFanout * d + 1, k = 0; k < (uint32_t)kWakeFanout && c < n; ++c, ++k) wake_job(s, c);
+    const uint32_t f = (uint32_t)s->wake_fanout, r = (uint32_t)s->wake_roots;
+    for (uint32_t c = r + f * d, k = 0; k < f && c < n; ++c, ++k) wake_job(s, c);
+}
+
+void wake_roots(Slot* s)
+{
+    const uint32_t n = s->n_val + s->n_fill;
+    for (uint32_t c = 0; c < (uint32_t)s->wake_roots && c < n; ++c) wake_job(s, c);
 }
 
 // The batch of a slot whose ticket was closed at `t`: waits for the callers
@@ -367,6 +379,8 @@ void process_batch(Slot* s, uint64_t t, bool blocking, uint64_t* phase_ns)
     s->val_bytes = (size_t)t_val_units(t) * kUnit;
     s->fill_bytes = (size_t)t_fill_units(t) * kUnit;
     s->max_job_bytes = 0;                                        // every job of a shared slot is small
+    s->wake_fanout = g_wake_fanout.load(std::memory_order_relaxed);
+    s->wake_roots = g_wake_roots.load(std::memory_order_relaxed);
     const uint32_t n_jobs = s->n_val + s->n_fill;
     const uint64_t t0 = now_ns();
     for (int spin = 0; s->written.load(std::memory_order_acquire) != n_jobs; ++spin)
@@ -379,7 +393,7 @@ void process_batch(Slot* s, uint64_t t, bool blocking, uint64_t* phase_ns)
     const uint64_t t3 = now_ns();
     if (rc) note_failure(*s);
     s->readers.store((int)n_jobs, std::memory_order_relaxed);
-    wake_job(s, 0);
+    wake_roots(s);
     if (phase_ns) {
         phase_ns[0] = t1 - t0; phase_ns[1] = t2 - t1; phase_ns[2] = t3 - t2; phase_ns[3] = now_ns() - t3;
     }
@@ -573,6 +587,10 @@ void execute(Job& job)
     (job.is_fill ? s->fdescs : s->vdescs)[idx] = job.desc;
     if (!job.is_fill) std::memcpy(s->up_host + off, job.in, bytes);
     s->written.fetch_add(1, std::memory_order_release);
+    if (const int spin_ns = g_spin_ns.load(std::memory_order_relaxed)) {
+        const uint64_t until = now_ns() + (uint64_t)spin_ns;
+        while (word->load(std::memory_order_acquire) == seq && now_ns() < until) __builtin_ia32_pause();
+    }
     while (word->load(std::memory_order_acquire) == seq) futex_wait(word, seq);
     wake_children(s, job.is_fill ? s->n_val + idx : idx);        // pass the wake-up on
     if (s->failed) {
@@ -591,6 +609,14 @@ void set_lanes(int lanes, int blocking)
     std::lock_guard<std::mutex> lk(g.mu);
     if (lanes >= 1) g.n_lanes = lanes > kMaxLanes ? kMaxLanes : lanes;
     if (blocking >= 0) g.blocking = blocking ? 1 : 0;
+}
+
+void set_caller_spin(int ns) { g_spin_ns.store(ns < 0 ? 0 : ns, std::memory_order_relaxed); }
+
+void set_wake_tree(int fanout, int roots)
+{
+    if (fanout >= 1) g_wake_fanout.store(fanout > 64 ? 64 : fanout, std::memory_order_relaxed);
+    if (roots >= 1) g_wake_roots.store(roots > 64 ? 64 : roots, std::memory_order_relaxed);
 }
 
 void set_batching(bool enable, int window_us, size_t /*max_bytes*/)

@@ -40,6 +40,11 @@ void set_batching(bool enable, int window_us, size_t max_bytes);
 // interrupt while their batch is on the device instead of polling.  Takes
 // effect when batching is next enabled.
 void set_lanes(int lanes, int blocking);
+// Shape of the tree through which the callers of a finished batch wake each other: the lane wakes
+// `roots` callers, each caller wakes `fanout` more (defaults 1 and 4; values < 1 keep the setting).
+void set_wake_tree(int fanout, int roots);
+// A caller polls its wake word this long before it sleeps on it (default 0: sleep at once).
+void set_caller_spin(int ns);
 void stats(uint64_t* batches, uint64_t* jobs);
 // Where the lane threads' time went since the last reset, summed over lanes:
 // ns waiting for callers still copying in, ns enqueueing, ns waiting for the

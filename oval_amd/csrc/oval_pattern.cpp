@@ -240,6 +240,12 @@ void SetMicroBatching(bool enable, int windowMicros, size_t maxBytes)
 
 void SetBatchLanes(int lanes, int blockingSync) { engine::set_lanes(lanes, blockingSync); }
 
+void SetWakeTuning(int fanout, int roots, int spinNanos)
+{
+    engine::set_wake_tree(fanout, roots);
+    if (spinNanos >= 0) engine::set_caller_spin(spinNanos);
+}
+
 void MicroBatchingStats(uint64_t* batches, uint64_t* jobs) { engine::stats(batches, jobs); }
 
 void LaneProfile(uint64_t out[8], bool reset) { engine::lane_profile(out, reset); }
@@ -1003,6 +1009,8 @@ void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes)
 }
 
 void oval_pattern_set_lanes(int lanes, int blocking_sync) { oval::pattern::SetBatchLanes(lanes, blocking_sync); }
+
+void oval_pattern_set_wake_tuning(int fanout, int roots, int spin_ns) { oval::pattern::SetWakeTuning(fanout, roots, spin_ns); }
 
 void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs)
 {

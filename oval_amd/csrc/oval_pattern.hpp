@@ -175,6 +175,10 @@ void MicroBatchingStats(uint64_t* batches, uint64_t* jobs);
 // (1) or polls (0) while its batch is on the device; negative / zero lanes keep
 // the current value.  Applies from the next SetMicroBatching(true).
 void SetBatchLanes(int lanes, int blockingSync);
+// How the callers of a finished batch are woken (the lane wakes `roots` of them, each wakes `fanout`
+// more; defaults 1 and 4) and how long a caller polls before it sleeps (default 0).  Values < 0 keep
+// the setting.  For benchmarks.
+void SetWakeTuning(int fanout, int roots, int spinNanos);
 // Time the lane threads spent per phase since the last reset, summed over
 // lanes: [0] ns waiting for callers still copying their bodies in, [1] ns
 // enqueueing the batch, [2] ns waiting for the device, [3] ns publishing and

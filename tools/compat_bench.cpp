@@ -6,6 +6,7 @@
 //   hipcc -O2 -std=c++17 -o build/compat_bench tools/compat_bench.cpp -Ioval_amd/csrc -Loval_amd -loval_hip -Wl,-rpath,$PWD/oval_amd -lpthread
 //
 //   compat_bench [seconds] [threads,threads,...] [lanes,lanes,...] [blocking 0|1|2 (2 = both)] [skip the unbatched run 0|1]
+//                [wake fan-out] [wake roots] [caller spin ns]
 #include <sys/resource.h>
 
 #include <atomic>
@@ -102,8 +103,11 @@ int main(int argc, char** argv)
     const std::vector<int> lanes = ints(argc > 3 ? argv[3] : "4");
     const int blocking = argc > 4 ? atoi(argv[4]) : 0;
     const bool skip_off = argc > 5 && atoi(argv[5]) != 0;
+    const int fanout = argc > 6 ? atoi(argv[6]) : -1, roots = argc > 7 ? atoi(argv[7]) : -1, spin = argc > 8 ? atoi(argv[8]) : -1;
     if (pattern::Init(0) != 0) { std::fprintf(stderr, "init failed: %s\n", pattern::LastEngineError().c_str()); return 1; }
     pattern::Seed(1);
+    pattern::SetWakeTuning(fanout, roots, spin);
+    if (argc > 6) std::printf("wake tree: fan-out %d, roots %d, caller spin %d ns (negative = default)\n", fanout, roots, spin);
     std::printf("host threads available to this process: %u\n", std::thread::hardware_concurrency());
     for (int n : threads) {
         if (!skip_off) run(n, secs, false, 1, 0);
