@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--verify-oracle", action="store_true",
                     help="rank 0 recomputes every rank's shard with the CPU oracle and requires the all-reduced "
                          "counters to equal the oracle's over the whole batch (small --objects only)")
+    ap.add_argument("--verify-plan", action="store_true",
+                    help="require the all-reduced counters to equal what the damage plans of all ranks imply "
+                         "(no CPU pass over the bodies: works at full size)")
     ap.add_argument("--sharding", default="workers", choices=["workers", "process"],
                     help="workers: one key space cut into worker ranges (default); process: rank r = process ID r")
     ap.add_argument("--seed", type=int, default=1)
@@ -215,7 +218,7 @@ def main():
     import torch
 
     from oval_amd import engine
-    from oval_amd.batch import DeviceCorruption, plan_corruption, span_bytes, split_batches
+    from oval_amd.batch import DeviceCorruption, expected_counters, plan_corruption, span_bytes, split_batches
     from oval_amd.dist import all_reduce, all_reduce_counters
 
     rank = int(os.environ.get("RANK", "0"))
@@ -269,10 +272,13 @@ def main():
     results = [torch.empty((len(p), 4), dtype=torch.int32, device=body.device) for p in parts]
     counters = torch.zeros(engine.NUM_COUNTERS, dtype=torch.int64, device=body.device)
     damage = None
+    planned = np.zeros(engine.NUM_COUNTERS, dtype=np.uint64)
+    planned[0], planned[2] = n_obj, units
     if args.corrupt > 0:
         # sub-batch k of rank r is damaged with seed (seed, r, k): reproducible on any other rank
-        damage = [DeviceCorruption(p, plan_corruption(p, args.corrupt, seed=args.seed * 1000003 + rank * 1009 + k),
-                                   body.device) for k, p in enumerate(parts)]
+        plans = [plan_corruption(p, args.corrupt, seed=args.seed * 1000003 + rank * 1009 + k) for k, p in enumerate(parts)]
+        damage = [DeviceCorruption(p, pl, body.device) for p, pl in zip(parts, plans)]
+        planned = sum(expected_counters(p, pl) for p, pl in zip(parts, plans))
 
     def step(timers=None):
         counters.zero_()
@@ -319,6 +325,18 @@ def main():
     assert int(tot[2]) == int(units_all), (int(tot[2]), units_all)
     if not damage:
         assert int(tot[1]) == 0 and int(tot[3]) == 0, f"clean batch reported corrupt: {tot}"
+    plan_ok = None
+    if args.verify_plan:
+        # what every rank's plan implies, gathered as plain lists (not through the all-reduce under test)
+        mine = [int(x) for x in planned]
+        if dist:
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+        else:
+            every = [mine]
+        want = np.sum(np.array(every, dtype=np.uint64), axis=0)
+        assert np.array_equal(tot.astype(np.uint64), want), f"counters {tot} differ from the plans' {want}"
+        plan_ok = True
     verified = None
     if args.verify_oracle and rank == 0:
         # the whole job on the CPU: every rank's shard, its damage, the oracle's counters summed
@@ -390,6 +408,8 @@ def main():
             out["counters"] = [int(x) for x in tot]
         if verified is not None:
             out["counters_equal_oracle"] = True
+        if plan_ok:
+            out["counters_equal_plan"] = True
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(descs, args.cpu_seconds)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -289,6 +289,37 @@ def apply_corruption_torch(body, descs: np.ndarray, plan: CorruptionPlan) -> Non
         body[idx] = body[idx] ^ torch.from_numpy(m).to(dev)
 
 
+def expected_counters(descs: np.ndarray, plan: CorruptionPlan) -> np.ndarray:
+    """The 12 batch counters a validate pass must report for a batch that was
+    filled and then damaged by `plan`, derived from the plan alone (no body
+    needed, so it works at sizes no CPU pass can reach).
+
+    Every planned unit is damaged exactly once (plan_corruption draws distinct
+    units).  A stale unit differs in its write count (and its never-compared
+    time); a bit flip is visible to the reference iff it lands in bytes [0, 40)
+    of the unit (pattern.go:136-170 reads nothing else) -- a flipped name byte can
+    never be trimmed away, since names are ASCII without white space inside and a
+    12-byte key fills its field -- and visible to the strict count unless it lands
+    in the time bytes [40, 48)."""
+    from ._lib import NUM_COUNTERS
+
+    c = np.zeros(NUM_COUNTERS, dtype=np.uint64)
+    c[0] = len(descs)
+    c[2] = int(descs["n_units"].astype(np.int64).sum())
+    pos = (plan.flip_byte % UNIT).astype(np.int64)
+    ref = pos < 40
+    field = [(pos < 16), (pos >= 16) & (pos < 28), (pos >= 28) & (pos < 32), (pos >= 32) & (pos < 36),
+             (pos >= 36) & (pos < 40)]
+    n_stale = len(plan.stale_obj)
+    c[3] = int(ref.sum()) + n_stale
+    c[4], c[5] = int(field[0].sum()), int(field[1].sum())
+    c[6] = int(field[2].sum()) + n_stale
+    c[7], c[8] = int(field[3].sum()), int(field[4].sum())
+    c[9] = int(((pos < 40) | (pos >= 48)).sum()) + n_stale
+    c[1] = len(np.unique(np.concatenate([plan._flip_obj[ref], plan.stale_obj])))
+    return c
+
+
 class DeviceCorruption:
     """A corruption plan resident on the device, for loops that re-apply it after
     every fill (benchmarks of the cfg4 / cfg5 shape)."""

@@ -165,3 +165,18 @@ def test_build_descs_flags_what_the_fast_compare_would_miss(oracle):
     assert list(res["bad_units"]) == [0, 2, 2, 2]
     with pytest.raises(ValueError):
         build_descs("b", np.full((1, 12), 0xC3, dtype=np.uint8), [1], [1], 5, 256)
+
+
+@pytest.mark.parametrize("seed,fraction", [(1, 1e-3), (2, 2e-2), (3, 0.3)])
+def test_expected_counters_from_the_plan_equal_the_oracle(oracle, seed, fraction):
+    """The plan-derived counters (used to check batches too large for any CPU
+    pass) agree with the oracle run over the damaged bytes."""
+    from oval_amd.batch import WorkerSpace, expected_counters, synthetic_batch
+
+    d = synthetic_batch(WorkerSpace(600, 3, start_worker_id=9), range(3), "test-bucket", 4096, 65536, seed=seed, unix_micro=77)
+    plan = plan_corruption(d, fraction, seed=seed)
+    body = np.zeros(span_bytes(d), dtype=np.uint8)
+    oracle.fill_batch(d.view(oracle.DESC_DTYPE), body)
+    apply_corruption_numpy(body, d, plan)
+    _, cnt = oracle.validate_batch(d.view(oracle.DESC_DTYPE), body)
+    assert np.array_equal(expected_counters(d, plan), cnt), (expected_counters(d, plan), cnt)

@@ -74,3 +74,20 @@ def test_capi_collective_refuses_more_ranks_than_gpus():
                         "--warmup", "0", "--cpu-seconds", "0"], cwd=ROOT, capture_output=True, text=True, timeout=280)
     assert p.returncode != 0
     assert "needs one GPU per rank" in p.stderr
+
+
+def test_cfg5_share_of_one_gpu_at_full_size_with_damage():
+    """cfg5's per-GPU share at its real size (1.25 M objects of 4k-1M, ~583 GB,
+    run as resident sub-batches through one body buffer), damaged at 1e-5 of its
+    units after each fill: every unit checked, and all 12 counters equal what the
+    damage plans imply (tests/test_batch.py checks that derivation against the
+    oracle at sizes a CPU pass can reach)."""
+    d = _one_line([sys.executable, "bench.py", "--workload", "cfg5", "--corrupt", "1e-5", "--verify-plan",
+                   "--steps", "1", "--warmup", "0", "--cpu-seconds", "0"])
+    assert d["counters_equal_plan"] is True
+    c = d["counters"]
+    assert d["config"]["bytes_per_gpu"] > 500e9 and d["config"]["sub_batches"] >= 8
+    assert c[0] == d["config"]["objects_per_gpu"] and c[2] == d["config"]["units_per_gpu"]
+    # ~1e-5 of 2.28 G units are damaged: half stale (all reference-visible), half by one bit flip, of
+    # which 40/256 land in the five compared fields and 248/256 outside the time bytes
+    assert 12000 < c[3] < 14500 and 10500 < c[6] < 12500 and 21000 < c[9] < 24000
