@@ -247,8 +247,13 @@ struct WRun {
     uint32_t sfirst;  // lowest global unit index with any mismatch (filler included)
 };
 
+// Per-field tallies stay in a vector register until the wavefront ends: every
+// field is judged by one fixed lane of a unit, so that lane counts its own
+// verdicts (at most four, one per wavefront instruction) in a 6-bit slot of
+// `fields`, and the twelve header lanes are added up once (w_totals_flush).
 struct WTotals {
-    uint32_t units, bucket, key, wc, off, wid, strict, objs;
+    uint32_t units, strict, objs;   // wave-uniform
+    uint32_t fields;                // per lane: bucket | key << 6 | write count << 12 | offset << 18 | worker << 24
 };
 
 // Bad-unit tallies go to one of kTallyStripes copies of the counter vector (one
@@ -299,84 +304,91 @@ __device__ __forceinline__ void w_flush(oval_obj_result* __restrict__ results,
 __device__ __forceinline__ void w_totals_flush(unsigned long long* __restrict__ stripes, const WTotals& tot,
                                                int lane)
 {
-    if (stripes && tot.strict != 0u && lane == 0) {
+    if (!stripes || tot.strict == 0u) return;
+    // lanes 16 g + 0 / 1 / 2 hold disjoint slots (bucket; key, write count; offset, worker): at most 16 per slot
+    uint32_t f = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        f += (uint32_t)__builtin_amdgcn_readlane((int)tot.fields, 16 * g) +
+             (uint32_t)__builtin_amdgcn_readlane((int)tot.fields, 16 * g + 1) +
+             (uint32_t)__builtin_amdgcn_readlane((int)tot.fields, 16 * g + 2);
+    if (lane == 0) {
         unsigned long long* counters = tally_of(stripes);
+        const uint32_t bucket = f & 63u, key = (f >> 6) & 63u, wc = (f >> 12) & 63u, off = (f >> 18) & 63u, wid = (f >> 24) & 63u;
         if (tot.objs) atomicAdd(&counters[OVAL_CNT_OBJECTS_BAD], (unsigned long long)tot.objs);
         if (tot.units) atomicAdd(&counters[OVAL_CNT_UNITS_BAD], (unsigned long long)tot.units);
-        if (tot.bucket) atomicAdd(&counters[OVAL_CNT_BAD_BUCKET], (unsigned long long)tot.bucket);
-        if (tot.key) atomicAdd(&counters[OVAL_CNT_BAD_KEY], (unsigned long long)tot.key);
-        if (tot.wc) atomicAdd(&counters[OVAL_CNT_BAD_WRITECNT], (unsigned long long)tot.wc);
-        if (tot.off) atomicAdd(&counters[OVAL_CNT_BAD_OFFSET], (unsigned long long)tot.off);
-        if (tot.wid) atomicAdd(&counters[OVAL_CNT_BAD_WORKER], (unsigned long long)tot.wid);
+        if (bucket) atomicAdd(&counters[OVAL_CNT_BAD_BUCKET], (unsigned long long)bucket);
+        if (key) atomicAdd(&counters[OVAL_CNT_BAD_KEY], (unsigned long long)key);
+        if (wc) atomicAdd(&counters[OVAL_CNT_BAD_WRITECNT], (unsigned long long)wc);
+        if (off) atomicAdd(&counters[OVAL_CNT_BAD_OFFSET], (unsigned long long)off);
+        if (wid) atomicAdd(&counters[OVAL_CNT_BAD_WORKER], (unsigned long long)wid);
         atomicAdd(&counters[OVAL_CNT_STRICT_UNITS_BAD], (unsigned long long)tot.strict);
     }
 }
 
 // Exact per-field outcome of one lane's 16 bytes (pattern.go:140-170); only
 // reached for a unit that failed the 128-bit compare or whose descriptor asks
-// for the exact check.
+// for the exact check.  The numeric fields are selects on the XOR of the lane's
+// bytes with its template; the one divergent branch is the TrimSpace compare of
+// a name field, taken only by a name lane whose bytes differ from the formatted
+// expected name (or whose expected name has white space at an edge, `force`):
+// a stale generation, where only the write count differs, never takes it.
 __device__ __forceinline__ uint32_t lane_field_mask(const u32x4& v, uint32_t ex, const u32x4& tmpl, uint32_t lf,
                                                     uint32_t force, int j)
 {
-    uint32_t fm = 0;
-    // A name field that equals the formatted expected name byte for byte is
-    // accepted without trimming (unless the expected name itself has white
-    // space at an edge, `force`): the usual case for a stale generation, where
-    // only the write count differs.
-    if (j == 0) {
-        const int blen = (int)(lf & 0xFFu);
-        const bool same = !force && v.x == tmpl.x && v.y == tmpl.y && v.z == tmpl.z && v.w == tmpl.w;
-        if (!same && !trimmed_equals([&](int i) { return reg_byte(v, i); }, 16,
-                                     [&](int i) { return reg_byte(tmpl, i); }, blen))
-            fm |= OVAL_BAD_BUCKET;
-    } else if (j == 1) {
-        const int klen = (int)((lf >> 8) & 0xFFu);
-        const bool same = !force && v.x == tmpl.x && v.y == tmpl.y && v.z == tmpl.z;
-        if (!same && !trimmed_equals([&](int i) { return reg_byte(v, i); }, 12,
-                                     [&](int i) { return reg_byte(tmpl, i); }, klen))
-            fm |= OVAL_BAD_KEY;
-        if (v.w != tmpl.w) fm |= OVAL_BAD_WRITECNT;
-    } else if (j == 2) {
-        if (v.x != ex) fm |= OVAL_BAD_OFFSET;
-        if (v.y != tmpl.y || force) fm |= OVAL_BAD_WORKER;     // force: worker ID outside uint32
-    } else {
-        fm = OVAL_BAD_FILLER;
+    const uint32_t dx = v.x ^ ex, dy = v.y ^ tmpl.y, dz = v.z ^ tmpl.z, dw = v.w ^ tmpl.w;
+    uint32_t fm = (j >= 3) ? OVAL_BAD_FILLER : 0u;
+    fm |= (j == 1 && dw != 0u) ? OVAL_BAD_WRITECNT : 0u;
+    fm |= (j == 2 && dx != 0u) ? OVAL_BAD_OFFSET : 0u;
+    fm |= (j == 2 && (dy | force) != 0u) ? OVAL_BAD_WORKER : 0u;    // force: worker ID outside uint32
+    const uint32_t name_diff = dx | dy | dz | (j == 0 ? dw : 0u);    // bucket: 16 bytes, key: the first 12
+    if (j < 2 && (name_diff | force) != 0u) {
+        const int width = j == 0 ? 16 : 12;
+        const int len = (int)((j == 0 ? lf : lf >> 8) & 0xFFu);
+        if (!trimmed_equals([&](int i) { return reg_byte(v, i); }, width, [&](int i) { return reg_byte(tmpl, i); }, len))
+            fm |= j == 0 ? OVAL_BAD_BUCKET : OVAL_BAD_KEY;
     }
     return fm;
 }
 
 // Exact verdict for the lanes flagged `bad` in one wavefront instruction (four
-// units, the flagged ones all inside object w): per-field masks, then a ballot
-// over the wavefront gives the lowest bad unit and the number of bad units.
+// units, the flagged ones all inside object w).  Every field is judged by one
+// fixed lane of a unit's sixteen (bucket: lane 0; key and write count: lane 1;
+// offset and worker: lane 2; filler: lanes 3-15), so one ballot per field puts
+// the verdicts of all four units into a scalar register, at bit 16 u + that lane;
+// shifted down to bit 16 u they combine with scalar ORs: no cross-lane traffic.
 __device__ __forceinline__ void w_handle_bad(const u32x4& v, uint32_t ex, const u32x4& tmpl, uint32_t lf,
                                              uint32_t force, bool bad, int j, uint32_t g4, WRun& r, WTotals& t)
 {
-    uint32_t fm = bad ? lane_field_mask(v, ex, tmpl, lf, force, j) : 0u;
-    fm |= __shfl_xor(fm, 1);
-    fm |= __shfl_xor(fm, 2);
-    fm |= __shfl_xor(fm, 4);
-    fm |= __shfl_xor(fm, 8);                                    // the unit's mask in all 16 lanes of its group
-    const uint32_t ref = fm & OVAL_REF_FIELDS;
-    const unsigned long long refb = __ballot(ref != 0u);
-    const unsigned long long anyb = __ballot(fm != 0u);
-    if (refb) {
-        const uint32_t first_lane = (uint32_t)__builtin_ctzll(refb);
+    const uint32_t fm = bad ? lane_field_mask(v, ex, tmpl, lf, force, j) : 0u;
+    const unsigned long long bb = __ballot((fm & OVAL_BAD_BUCKET) != 0u);
+    const unsigned long long bk = __ballot((fm & OVAL_BAD_KEY) != 0u) >> 1;
+    const unsigned long long bw = __ballot((fm & OVAL_BAD_WRITECNT) != 0u) >> 1;
+    const unsigned long long bo = __ballot((fm & OVAL_BAD_OFFSET) != 0u) >> 2;
+    const unsigned long long bi = __ballot((fm & OVAL_BAD_WORKER) != 0u) >> 2;
+    const unsigned long long bf = __ballot((fm & OVAL_BAD_FILLER) != 0u);
+    const unsigned long long refu = bb | bk | bw | bo | bi;    // bit 16 u: unit u has a reference-visible mismatch
+    // bit 16 u + 15 of `fu`: some filler lane of unit u is set (a carry out of the low 15 bits, or bit 15 itself)
+    unsigned long long fu = ((bf & 0x7FFF7FFF7FFF7FFFull) + 0x7FFF7FFF7FFF7FFFull) | bf;
+    fu = (fu >> 15) & 0x0001000100010001ull;
+    const unsigned long long anyu = refu | fu;
+    // this lane's own verdicts, one slot per field (the mask bits are 1, 2, 4, 8, 16)
+    t.fields += (fm & 1u) | ((fm & 2u) << 5) | ((fm & 4u) << 10) | ((fm & 8u) << 15) | ((fm & 16u) << 20);
+    if (refu) {
+        const uint32_t sh = (uint32_t)__builtin_ctzll(refu);    // 16 x the lowest bad unit
         if (r.cnt == 0u) {                                      // units arrive in ascending order
-            r.first = g4 + (first_lane >> 4);
-            r.mask = (uint32_t)__builtin_amdgcn_readlane((int)ref, (int)first_lane);
+            r.first = g4 + (sh >> 4);
+            r.mask = (uint32_t)((bb >> sh) & 1ull) * OVAL_BAD_BUCKET | (uint32_t)((bk >> sh) & 1ull) * OVAL_BAD_KEY |
+                     (uint32_t)((bw >> sh) & 1ull) * OVAL_BAD_WRITECNT | (uint32_t)((bo >> sh) & 1ull) * OVAL_BAD_OFFSET |
+                     (uint32_t)((bi >> sh) & 1ull) * OVAL_BAD_WORKER;
         }
-        const uint32_t n = (uint32_t)__builtin_popcountll(refb) >> 4;
+        const uint32_t n = (uint32_t)__builtin_popcountll(refu);
         r.cnt += n;
         t.units += n;
-        t.bucket += (uint32_t)__builtin_popcountll(__ballot((ref & OVAL_BAD_BUCKET) != 0u)) >> 4;
-        t.key += (uint32_t)__builtin_popcountll(__ballot((ref & OVAL_BAD_KEY) != 0u)) >> 4;
-        t.wc += (uint32_t)__builtin_popcountll(__ballot((ref & OVAL_BAD_WRITECNT) != 0u)) >> 4;
-        t.off += (uint32_t)__builtin_popcountll(__ballot((ref & OVAL_BAD_OFFSET) != 0u)) >> 4;
-        t.wid += (uint32_t)__builtin_popcountll(__ballot((ref & OVAL_BAD_WORKER) != 0u)) >> 4;
     }
-    if (anyb) {
-        if (r.sfirst == kNone) r.sfirst = g4 + ((uint32_t)__builtin_ctzll(anyb) >> 4);
-        t.strict += (uint32_t)__builtin_popcountll(anyb) >> 4;
+    if (anyu) {
+        if (r.sfirst == kNone) r.sfirst = g4 + ((uint32_t)__builtin_ctzll(anyu) >> 4);
+        t.strict += (uint32_t)__builtin_popcountll(anyu);
     }
 }
 
@@ -439,7 +451,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     tmpl = w_lane_template(w, j, cpat);
     force = w_lane_force(w, j);
     WRun run = {kNone, 0, 0, kNone};
-    WTotals tot = {0, 0, 0, 0, 0, 0, 0, 0};
+    WTotals tot = {0, 0, 0, 0};
 #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
         const uint32_t g4 = g0 + 4u * i;
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(256) void host_batch_kernel(sdesc_ptr vdescs, sdesc
     const uint32_t zwmask = (j == 2) ? 0u : 0xFFFFFFFFu;       // pattern.go:172 "Skip the unix time area."
     const uint32_t force = w_lane_force(w, j);
     WRun run = {kNone, 0, 0, kNone};
-    WTotals tot = {0, 0, 0, 0, 0, 0, 0, 0};
+    WTotals tot = {0, 0, 0, 0};
     // 64 units (16 KiB) per round of the workgroup: four loads per thread in flight
     for (uint32_t base = w.start; base < w.end; base += 64u) {
         u32x4 v[4];

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--objects", type=int, default=1_000_000)
     ap.add_argument("--lib", default="", help="another build of the library (kernel experiments)")
+    ap.add_argument("--fractions", default="0,1e-4,1e-3,1e-2,1e-1,1", help="stale fractions to run, comma separated")
     ap.add_argument("--no-check", action="store_true", help="do not compare the counters (timing-only experiments)")
     args = ap.parse_args()
     if args.lib:
@@ -36,7 +37,7 @@ def main():
     results = torch.empty((n, 4), dtype=torch.int32, device="cuda:0")
     counters = torch.zeros(engine.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
     rng = np.random.default_rng(7)
-    for frac in (0.0, 1e-4, 1e-3, 1e-2, 1e-1, 1.0):
+    for frac in [float(x) for x in args.fractions.split(",")]:
         d2 = descs.copy()
         stale = rng.random(n) < frac
         d2["write_count"][stale] += 1
