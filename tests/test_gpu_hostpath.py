@@ -280,3 +280,86 @@ def test_valid_streams_a_256_mib_body_behind_a_dribbling_reader(oracle):
         assert text.startswith("could not read some data. (expected: 256byte, actual: 232byte)")
     finally:
         pattern.set_clock(-1)
+
+
+def test_every_host_path_at_once_while_batching_toggles(oracle):
+    """Worker threads mixing small Generate / Valid calls (micro-batched), bodies
+    too large to share a slot, multipart generation and streamed validation, while
+    another thread switches micro-batching on and off: every call returns what
+    the oracle says, whichever path it happened to take."""
+    import threading
+    import time
+
+    from oval_amd import pattern
+    from oval_amd.object import Object
+
+    pattern.init(0)
+    pattern.set_clock(T0)
+    pattern.set_stream_chunk(1 << 20)
+    stop = threading.Event()
+    errors = []
+
+    def toggler():
+        on = False
+        while not stop.is_set():
+            on = not on
+            pattern.set_batching(on, window_us=0)
+            time.sleep(0.003)
+        pattern.set_batching(False)
+
+    def work(t):
+        rng = np.random.default_rng(1000 + t)
+        try:
+            for it in range(40):
+                kind = (t + it) % 4
+                wc, wid, b = int(rng.integers(1, 500)), 0x561B + t, "test-bucket"
+                key = "ov%010x" % (t * 1000 + it)
+                if kind == 0:                                           # small, shares launches
+                    size = 256 * int(rng.integers(1, 64))
+                elif kind == 1:                                         # too large for a shared slot
+                    size = 256 * int(rng.integers(1100, 3000))
+                else:
+                    size = 256 * int(rng.integers(5000, 20000))         # 1.2 - 5 MiB
+                obj = Object(key, size, wc)
+                want = oracle.generate(size, wid, b, key, wc, T0)
+                if kind == 2:
+                    with pattern.GenerateParts(size, wid, b, obj, 1 << 20) as parts:
+                        body = b"".join(parts.part(i).tobytes() for i in range(len(parts)))
+                else:
+                    body = pattern.Generate(size, wid, b, obj)
+                if body != want:
+                    errors.append((t, it, "generate"))
+                    continue
+                data = bytearray(body)
+                if it % 3 == 0:
+                    data[int(rng.integers(0, size))] ^= 1 << int(rng.integers(0, 8))
+                if it % 5 == 0:
+                    data = data[:int(rng.integers(0, size))]
+                data = bytes(data)
+                try:
+                    if kind == 3:
+                        pattern.ValidStream(wid, b, obj, io.BytesIO(data))    # chunks of 1 MiB through the double buffer
+                    else:
+                        pattern.Valid(wid, b, obj, data)
+                    got = None
+                except pattern.PatternError as e:
+                    got = str(e)
+                if got != oracle.valid(wid, b, key, size, wc, data)[2]:
+                    errors.append((t, it, "valid"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    tg = threading.Thread(target=toggler)
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(12)]
+    try:
+        tg.start()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        stop.set()
+        tg.join()
+        pattern.set_stream_chunk(32 << 20)
+        pattern.set_clock(-1)
+    assert not errors, errors[:5]
