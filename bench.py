@@ -176,6 +176,53 @@ def cpu_baseline(descs, budget_s):
     }
 
 
+def measure_traffic(argv_tail, kernel_prefix, is_fill, launches_per_pass):
+    """HBM bytes per launch of the dominant kernel from PMC counters, measured NOW
+    on this box: a child run of this same bench under `rocprofv3 --pmc` (one
+    counter, its own run; the profiler cannot be attached from inside).  Counter
+    units are KiB; FETCH_SIZE tallies the 128-byte requests of a wide streaming
+    read at 64 bytes each on gfx950, so read bytes = 2 x FETCH_SIZE x 1024.
+    Returns (bytes per launch, how) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this run is itself under a profiler"
+    counter = "WRITE_SIZE" if is_fill else "FETCH_SIZE"
+    passes = 3
+    out = tempfile.mkdtemp(prefix="oval_pmc_")
+    try:
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--steps", str(passes - 1), "--warmup", "1", "--cpu-seconds", "0",
+               "--no-traffic"] + argv_tail
+        p = subprocess.run(cmd, cwd=out, capture_output=True, text=True, timeout=240,
+                           env=dict(os.environ, TMPDIR="/tmp"))
+        if p.returncode != 0:
+            return None, f"rocprofv3 --pmc {counter} child failed (rc {p.returncode})"
+        total, n = 0.0, 0
+        for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == counter and ("oval::" + kernel_prefix) in r["Kernel_Name"]:
+                    total += float(r["Counter_Value"])
+                    n += 1
+        if n == 0:
+            return None, f"no {counter} rows for {kernel_prefix}"
+        per_pass = total * 1024.0 * (1.0 if is_fill else 2.0) / passes
+        return int(per_pass / max(launches_per_pass, 1)), (
+            f"measured in this run: child `rocprofv3 --pmc {counter}` of the same command, {n} launches over "
+            f"{passes} passes" + ("" if is_fill else ", x2 gfx950 FETCH_SIZE correction"))
+    except Exception as e:  # noqa: BLE001
+        return None, f"PMC child run failed: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +243,8 @@ def main():
     ap.add_argument("--verify-plan", action="store_true",
                     help="require the all-reduced counters to equal what the damage plans of all ranks imply "
                          "(no CPU pass over the bodies: works at full size)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic with a child rocprofv3 --pmc run (N=1 only; ~15 s)")
     ap.add_argument("--sharding", default="workers", choices=["workers", "process"],
                     help="workers: one key space cut into worker ranges (default); process: rank r = process ID r")
     ap.add_argument("--seed", type=int, default=1)
@@ -370,16 +419,25 @@ def main():
         dom, dom_ms, dom_gbs, dom_n = ((val_name, val_ms, val_gbs, n_val) if val_ms >= fill_ms
                                        else (fill_name, fill_ms, fill_gbs, n_fill))
         traffic, traffic_source = None, "none: no stored PMC pass for this shape"
+        if world == 1 and not args.no_traffic and not damage:
+            tail = ["--workload", args.workload, "--seed", str(args.seed), "--batch-gib", str(args.batch_gib),
+                    "--sharding", args.sharding]
+            if args.objects: tail += ["--objects", str(args.objects)]
+            if args.sizes: tail += ["--sizes", args.sizes]
+            if args.fill_threads: tail += ["--fill-threads", str(args.fill_threads)]
+            if args.validate_threads: tail += ["--validate-threads", str(args.validate_threads)]
+            is_fill = dom.startswith("fill")
+            traffic, traffic_source = measure_traffic(tail, "fill_kernel" if is_fill else "validate_kernel", is_fill, dom_n)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                if not (args.objects or args.sizes):             # measured on the default shape only
+                if traffic is None and not (args.objects or args.sizes):   # stored for the default shapes only
                     # the file holds HBM bytes per pass over the batch (PMC passes); per launch here
                     stored = json.load(open(tpath))
                     per_pass = stored.get(args.workload, {}).get(dom)
                     traffic = per_pass // max(dom_n, 1) if per_pass else None
                     if traffic:
-                        traffic_source = ("profiles/traffic.json: " + stored.get("source", "an earlier rocprofv3 --pmc pass")
+                        traffic_source = (traffic_source + "; fell back to profiles/traffic.json: " + stored.get("source", "an earlier rocprofv3 --pmc pass")
                                           + "; NOT measured in this run")
             except Exception:
                 traffic = None

@@ -13,7 +13,7 @@ groups=(
 )
 i=0
 for g in "${groups[@]}"; do
-  timeout -s KILL 120 rocprofv3 --pmc $g --output-format csv -d $R/gpurun_out/pmc_$tag/g$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 "$@" > $R/gpurun_out/pmc_$tag/g$i.log 2>&1 || echo "group $i failed"
+  timeout -s KILL 120 rocprofv3 --pmc $g --output-format csv -d $R/gpurun_out/pmc_$tag/g$i -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-traffic "$@" > $R/gpurun_out/pmc_$tag/g$i.log 2>&1 || echo "group $i failed"
   i=$((i+1))
 done
 python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_$tag
