@@ -421,13 +421,11 @@ GeneratedParts::~GeneratedParts()
 Error GeneratedParts::Part(int64_t i, const uint8_t** data, size_t* len)
 {
     if (i < 0 || i >= count_) return Error::New("oval engine failure: part index out of range");
-    engine::Parts* impl;
-    {
-        std::lock_guard<std::mutex> lk(*static_cast<std::mutex*>(mu_));
-        if (!impl_ || state_[(size_t)i] == 2) return Error::New("oval engine failure: part already released");
-        state_[(size_t)i] = 1;
-        impl = static_cast<engine::Parts*>(impl_);
-    }
+    // held across the wait: a Close() from another thread must not free the buffer under it
+    std::lock_guard<std::mutex> lk(*static_cast<std::mutex*>(mu_));
+    if (!impl_ || state_[(size_t)i] == 2) return Error::New("oval engine failure: part already released");
+    state_[(size_t)i] = 1;
+    engine::Parts* impl = static_cast<engine::Parts*>(impl_);
     const size_t begin = (size_t)(i * part_size_);
     const size_t end = (size_t)std::min<int64_t>(size_, (i + 1) * part_size_);
     std::string eng_err;
