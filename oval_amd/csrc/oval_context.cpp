@@ -6,8 +6,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
+#include <thread>
 
 namespace oval {
 
@@ -727,43 +729,129 @@ Error PopulateExisting(ExecutionContext& ec, uint64_t seed, double fraction, int
     return Error::Nil();
 }
 
+// One segment = the existing objects of one (worker, bucket) pair, in the order
+// of its existingObjectIDs.  Segments are independent, so the table is built in
+// two passes: sizes per segment (where each segment's descriptors and bodies
+// start), then the descriptors themselves, both spread over a few host threads:
+// for a million objects the table would otherwise take longer to build on one
+// core (70 ms) than to validate on the device (1.3 ms) fifty times over.
+namespace {
+
+struct Segment {
+    uint32_t worker = 0, bucket = 0;
+    size_t first = 0;          // index of its first descriptor
+    uint64_t units = 0;        // sum of its objects' units
+    uint64_t offset = 0;       // where its first body starts
+    Error err = Error::Nil();
+};
+
+template <class Fn>
+void for_each_segment(std::vector<Segment>& segs, size_t n_objects, const Fn& fn)
+{
+    size_t n_threads = n_objects / 50000;                      // a thread per ~50 K objects ...
+    const size_t hw = std::thread::hardware_concurrency();
+    if (n_threads > 8) n_threads = 8;                          // ... at most eight, at most one per core
+    if (hw && n_threads > hw) n_threads = hw;
+    if (n_threads > segs.size()) n_threads = segs.size();
+    if (n_threads <= 1) {
+        for (Segment& s : segs) fn(s);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < segs.size();) fn(segs[i]);
+    };
+    std::vector<std::thread> ts;
+    for (size_t t = 1; t < n_threads; ++t) ts.emplace_back(work);
+    work();
+    for (std::thread& t : ts) t.join();
+}
+
+}  // namespace
+
+Error BuildExistingDescriptorsInto(const ExecutionContext& ec, uint64_t unixMicro, size_t workerBegin, size_t workerEnd,
+                                   oval_obj_desc* descs, ObjectRef* refs, size_t cap, size_t* nOut, uint64_t* bodyBytesOut)
+{
+    if (workerEnd > ec.Workers.size()) workerEnd = ec.Workers.size();
+    std::vector<Segment> segs;
+    size_t n = 0;
+    for (size_t w = workerBegin; w < workerEnd; ++w)
+        for (size_t b = 0; b < ec.Workers[w].BucketsWithObject.size(); ++b) {
+            Segment s;
+            s.worker = (uint32_t)w;
+            s.bucket = (uint32_t)b;
+            s.first = n;
+            n += ec.Workers[w].BucketsWithObject[b].ObjectMeta.ExistingObjectIDs.size();
+            segs.push_back(std::move(s));
+        }
+    // pass 1: how many units each segment holds (and whether its IDs and sizes are sane)
+    for_each_segment(segs, n, [&](Segment& s) {
+        const object::ObjectMeta& om = ec.Workers[s.worker].BucketsWithObject[s.bucket].ObjectMeta;
+        uint64_t units = 0;
+        for (int64_t objID : om.ExistingObjectIDs) {
+            if (objID < 0 || (uint64_t)objID >= om.ObjectList.size()) {
+                s.err = Error::New("existingObjectIDs holds " + std::to_string(objID) + ", outside the object list");
+                return;
+            }
+            const object::Object& obj = om.ObjectList[(size_t)objID];
+            if (obj.Size < 0) { s.err = Error::New("object " + obj.Key + " has a negative size"); return; }
+            const uint64_t u = (uint64_t)obj.Size / (uint64_t)pattern::dataUnitSize;
+            if (u > UINT32_MAX) { s.err = Error::New("object " + obj.Key + " is too large"); return; }
+            units += u;
+        }
+        s.units = units;
+    });
+    uint64_t off = 0;
+    for (Segment& s : segs) {
+        if (!s.err.nil()) return s.err;                          // the first in table order
+        s.offset = off;
+        off += s.units * (uint64_t)pattern::dataUnitSize;
+    }
+    if (nOut) *nOut = n;
+    if (bodyBytesOut) *bodyBytesOut = off;
+    if (!descs && !refs) return Error::Nil();                    // the caller only asked how large the table is
+    // pass 2: the descriptors, bodies back to back in segment order; entries beyond `cap` are not written
+    for_each_segment(segs, n, [&](Segment& s) {
+        const Worker& wk = ec.Workers[s.worker];
+        const BucketWithObject& bo = wk.BucketsWithObject[s.bucket];
+        // Valid and Generate cut the bucket name to 16 bytes (pattern.go:74-76,119-121)
+        const std::string bucket = bo.BucketName.substr(0, object::MaxBucketNameLength);
+        uint64_t o = s.offset;
+        size_t i = s.first;
+        for (int64_t objID : bo.ObjectMeta.ExistingObjectIDs) {
+            if (i >= cap) return;
+            const object::Object& obj = bo.ObjectMeta.ObjectList[(size_t)objID];
+            const uint64_t units = (uint64_t)obj.Size / (uint64_t)pattern::dataUnitSize;
+            oval_obj_desc d;
+            const int rc = oval_desc_init(&d, bucket.data(), bucket.size(), obj.Key.data(), obj.Key.size(),
+                                          obj.WriteCount, wk.id, unixMicro, o, 0, (uint32_t)units);
+            if (rc != OVAL_OK) {
+                s.err = Error::New("object " + obj.Key + ": " + oval_last_error());   // this thread's message
+                return;
+            }
+            if (descs) descs[i] = d;
+            if (refs) refs[i] = ObjectRef{s.worker, s.bucket, objID};
+            o += units * (uint64_t)pattern::dataUnitSize;
+            ++i;
+        }
+    });
+    for (const Segment& s : segs)
+        if (!s.err.nil()) return s.err;
+    return Error::Nil();
+}
+
 std::pair<DescriptorTable, Error> BuildExistingDescriptors(const ExecutionContext& ec, uint64_t unixMicro,
                                                            size_t workerBegin, size_t workerEnd)
 {
     DescriptorTable t;
-    if (workerEnd > ec.Workers.size()) workerEnd = ec.Workers.size();
     size_t n = 0;
-    for (size_t w = workerBegin; w < workerEnd; ++w)
-        for (const BucketWithObject& b : ec.Workers[w].BucketsWithObject) n += b.ObjectMeta.ExistingObjectIDs.size();
-    t.descs.reserve(n);
-    t.refs.reserve(n);
-    uint64_t off = 0;
-    for (size_t w = workerBegin; w < workerEnd; ++w) {
-        const Worker& wk = ec.Workers[w];
-        for (size_t b = 0; b < wk.BucketsWithObject.size(); ++b) {
-            const BucketWithObject& bo = wk.BucketsWithObject[b];
-            // Valid and Generate cut the bucket name to 16 bytes (pattern.go:74-76,119-121)
-            const std::string bucket = bo.BucketName.substr(0, object::MaxBucketNameLength);
-            for (int64_t objID : bo.ObjectMeta.ExistingObjectIDs) {
-                if (objID < 0 || (uint64_t)objID >= bo.ObjectMeta.ObjectList.size())
-                    return {DescriptorTable(), Error::New("existingObjectIDs holds " + std::to_string(objID) +
-                                                          ", outside the object list")};
-                const object::Object& obj = bo.ObjectMeta.ObjectList[(size_t)objID];
-                if (obj.Size < 0) return {DescriptorTable(), Error::New("object " + obj.Key + " has a negative size")};
-                const uint64_t units = (uint64_t)obj.Size / (uint64_t)pattern::dataUnitSize;
-                if (units > UINT32_MAX) return {DescriptorTable(), Error::New("object " + obj.Key + " is too large")};
-                oval_obj_desc d;
-                const int rc = oval_desc_init(&d, bucket.data(), bucket.size(), obj.Key.data(), obj.Key.size(),
-                                              obj.WriteCount, wk.id, unixMicro, off, 0, (uint32_t)units);
-                if (rc != OVAL_OK)
-                    return {DescriptorTable(), Error::New("object " + obj.Key + ": " + oval_last_error())};
-                t.descs.push_back(d);
-                t.refs.push_back(ObjectRef{(uint32_t)w, (uint32_t)b, objID});
-                off += units * (uint64_t)pattern::dataUnitSize;
-            }
-        }
-    }
-    t.bodyBytes = off;
+    Error e = BuildExistingDescriptorsInto(ec, unixMicro, workerBegin, workerEnd, nullptr, nullptr, 0, &n, &t.bodyBytes);
+    if (!e.nil()) return {DescriptorTable(), e};
+    t.descs.resize(n);
+    t.refs.resize(n);
+    e = BuildExistingDescriptorsInto(ec, unixMicro, workerBegin, workerEnd, t.descs.data(), t.refs.data(), n, &n,
+                                     &t.bodyBytes);
+    if (!e.nil()) return {DescriptorTable(), e};
     return {std::move(t), Error::Nil()};
 }
 
@@ -1010,19 +1098,16 @@ int oval_execctx_build_descs(const oval_execctx* ec, uint64_t unix_micro, size_t
                              uint64_t* body_bytes_out, char* err, size_t err_cap)
 {
     if (!ec) return OVAL_E_INVALID;
-    auto r = oval::runner::BuildExistingDescriptors(ec->ec, unix_micro, worker_begin, worker_end);
-    if (!r.second.nil()) return put_err(r.second, err, err_cap);
-    const oval::runner::DescriptorTable& t = r.first;
-    if (n_out) *n_out = t.descs.size();
-    if (body_bytes_out) *body_bytes_out = t.bodyBytes;
-    const size_t n = t.descs.size() < cap ? t.descs.size() : (size_t)cap;
-    if (descs_out && n) std::memcpy(descs_out, t.descs.data(), n * sizeof(oval_obj_desc));
-    if (refs_out)
-        for (size_t i = 0; i < n; ++i) {
-            refs_out[i].worker = t.refs[i].worker;
-            refs_out[i].bucket = t.refs[i].bucket;
-            refs_out[i].obj_id = t.refs[i].objID;
-        }
+    static_assert(sizeof(oval_obj_ref) == sizeof(oval::runner::ObjectRef) && offsetof(oval_obj_ref, obj_id) == 8,
+                  "oval_obj_ref is ObjectRef");
+    size_t n = 0;
+    uint64_t bytes = 0;
+    const oval::Error e = oval::runner::BuildExistingDescriptorsInto(
+        ec->ec, unix_micro, worker_begin, worker_end, descs_out, reinterpret_cast<oval::runner::ObjectRef*>(refs_out),
+        (size_t)cap, &n, &bytes);
+    if (!e.nil()) return put_err(e, err, err_cap);
+    if (n_out) *n_out = n;
+    if (body_bytes_out) *body_bytes_out = bytes;
     return put_err(oval::Error::Nil(), err, err_cap);
 }
 

@@ -114,6 +114,10 @@ struct DescriptorTable {
 // workers [workerBegin, workerEnd) only (a rank's share, runner.go:117-124).
 std::pair<DescriptorTable, Error> BuildExistingDescriptors(const ExecutionContext& ec, uint64_t unixMicro,
                                                            size_t workerBegin, size_t workerEnd);
+// The same into the caller's arrays (either may be NULL; entries beyond `cap` are not written).  With
+// both NULL only *nOut and *bodyBytesOut are computed: how large a table the caller has to provide.
+Error BuildExistingDescriptorsInto(const ExecutionContext& ec, uint64_t unixMicro, size_t workerBegin, size_t workerEnd,
+                                   oval_obj_desc* descs, ObjectRef* refs, size_t cap, size_t* nOut, uint64_t* bodyBytesOut);
 uint64_t CountExisting(const ExecutionContext& ec);
 
 // Puts a context into the state a run leaves behind, without running one: every
