@@ -309,6 +309,13 @@ struct Reader {
         const char* s = p;
         if (p < end && *p == '-') ++p;
         if (p >= end || *p < '0' || *p > '9') { p = s; return fail(std::string("cannot unmarshal into field ") + field + " of type int"); }
+        // up to 18 digits cannot overflow: no detour through strtoll for the millions of small numbers of a context
+        uint64_t acc = 0;
+        while (p < end && *p >= '0' && *p <= '9' && p - s < 18) acc = acc * 10u + (uint64_t)(*p++ - '0');
+        if (p >= end || ((*p < '0' || *p > '9') && *p != '.' && *p != 'e' && *p != 'E')) {
+            out = *s == '-' ? -(int64_t)acc : (int64_t)acc;
+            return true;
+        }
         while (p < end && *p >= '0' && *p <= '9') ++p;
         if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) {
             p = s;
@@ -409,8 +416,50 @@ bool read_int_field(Reader& r, int64_t& dst, const char* name)
     return r.integer(dst, name);
 }
 
+// `{"key":"...","size":N,"writeCount":N}` exactly as encoding/json writes an Object (struct order, no
+// white space, a key without escapes): the shape of all but a handful of a saved context's bytes.  Anything
+// else is left to the general reader.
+bool read_object_entry_compact(Reader& r, object::Object& o)
+{
+    auto starts = [&](const char* q, const char* lit, size_t n) { return (size_t)(r.end - q) >= n && std::memcmp(q, lit, n) == 0; };
+    auto number = [&](const char*& q, int64_t& v) {
+        const char* s = q;
+        const bool neg = q < r.end && *q == '-';
+        if (neg) ++q;
+        const char* d = q;
+        uint64_t acc = 0;
+        while (q < r.end && *q >= '0' && *q <= '9' && q - d < 18) acc = acc * 10u + (uint64_t)(*q++ - '0');
+        if (q == d || (q < r.end && ((*q >= '0' && *q <= '9') || *q == '.' || *q == 'e' || *q == 'E'))) { q = s; return false; }
+        v = neg ? -(int64_t)acc : (int64_t)acc;
+        return true;
+    };
+    const char* q = r.p;
+    if (!starts(q, "{\"key\":\"", 8)) return false;
+    q += 8;
+    const char* k = q;
+    while (q < r.end && *q != '"' && *q != '\\' && (unsigned char)*q >= 0x20 && (unsigned char)*q < 0x80) ++q;
+    if (q >= r.end || *q != '"') return false;
+    const size_t klen = (size_t)(q - k);
+    ++q;
+    int64_t size = 0, wc = 0;
+    if (!starts(q, ",\"size\":", 8)) return false;
+    q += 8;
+    if (!number(q, size)) return false;
+    if (!starts(q, ",\"writeCount\":", 14)) return false;
+    q += 14;
+    if (!number(q, wc)) return false;
+    if (q >= r.end || *q != '}') return false;
+    r.p = q + 1;
+    o.Key.assign(k, klen);
+    o.Size = size;
+    o.WriteCount = wc;
+    return true;
+}
+
 bool read_object_entry(Reader& r, object::Object& o)
 {
+    r.ws();
+    if (read_object_entry_compact(r, o)) return true;
     return read_object(r, [&](const std::string& k) {
         if (key_is(k, "key")) return read_string_field(r, o.Key);
         if (key_is(k, "size")) return read_int_field(r, o.Size, "Object.size");

@@ -328,3 +328,36 @@ def test_existing_descriptors_at_a_size_that_takes_several_threads():
                         [o.Size for o in objs])
         d["body_offset"] += descs["body_offset"][sel[0]]
         assert descs[sel[:500]].tobytes() == d.tobytes()
+
+
+def test_object_entries_in_any_shape_load_alike():
+    """The reader has a short cut for object entries exactly as encoding/json
+    writes them; entries in any other legal shape (white space, another member
+    order, escapes in the key, unknown members, 19-digit numbers) take the general
+    route and must give the same objects."""
+    import json
+
+    def ctx(entries):
+        return ('{"endpoint":"e","bucketNames":["b"],"numObj":4,"numWorker":1,"minSize":256,"maxSize":512,'
+                '"startWorkerID":3,"workers":[{"bucketsWithObject":[{"bucketName":"b","objectMeta":{"objectList":['
+                + ",".join(entries) + '],"existingObjectIDs":[0,2],"keyIDOffset":0,"KeyPrefix":"ov0000"}}]}]}').encode()
+
+    compact = ['{"key":"ov0000000000","size":512,"writeCount":7}', '{"key":"ov0000000001","size":0,"writeCount":0}',
+               '{"key":"ov0000000002","size":256,"writeCount":922337203685477580}',
+               '{"key":"ov0000000003","size":-256,"writeCount":1}']
+    other = ['{ "key" : "ov0000000000" , "size" : 512 , "writeCount" : 7 }',
+             '{"writeCount":0,"size":0,"key":"ov000000000\\u0031","extra":[1,{"a":null}]}',
+             '{"key":"ov0000000002","size":256,"writeCount":922337203685477580,"KEY":"ov0000000002"}',
+             '{"key":"ov0000000003","size":-256,"writeCount":1}\n']
+    a = X.ExecutionContext.Load(ctx(compact))
+    b = X.ExecutionContext.Load(ctx(other))
+    assert a.Marshal() == b.Marshal()
+    tree = json.loads(a.Marshal())
+    objs = tree["workers"][0]["bucketsWithObject"][0]["objectMeta"]["objectList"]
+    assert [o["key"] for o in objs] == ["ov000000000%d" % i for i in range(4)]
+    assert [o["size"] for o in objs] == [512, 0, 256, -256] and objs[2]["writeCount"] == 922337203685477580
+    # numbers beyond int64 and non-integers are errors on either route
+    for bad in ('{"key":"k","size":92233720368547758070,"writeCount":1}', '{"key":"k","size":1.5,"writeCount":1}',
+                '{"key":"k","size":1e3,"writeCount":1}'):
+        with pytest.raises(Exception):
+            X.ExecutionContext.Load(ctx([bad]))
