@@ -306,14 +306,22 @@ void ensure_inited_locked()
     g.inited = true;
 }
 
+// Generated bodies (parts_open) keep their slot until their last slice has landed, but nobody is told
+// when that happens: whoever finds no slot free looks whether one of them is done (defined below).
+bool reap_finished_parts();
+
 // A free slot for the caller's exclusive use.
 Slot* acquire_slot()
 {
     std::unique_lock<std::mutex> lk(g.mu);
     ensure_inited_locked();
     while (g.free_slots.empty()) {
+        lk.unlock();
+        const bool reaped = reap_finished_parts();
+        lk.lock();
+        if (reaped || !g.free_slots.empty()) continue;
         g.slot_waiters++;
-        g.slot_cv.wait(lk);
+        g.slot_cv.wait_for(lk, std::chrono::microseconds(200));   // a landed body frees its slot without a notify
         g.slot_waiters--;
     }
     Slot* s = g.free_slots.back();
@@ -562,8 +570,12 @@ void execute(Job& job)
         } else if (o != c || !full) {
             continue;                                            // it changed while the lock was taken
         }
+        lk.unlock();
+        if (reap_finished_parts()) continue;                     // a landed body was still holding a slot
+        lk.lock();
+        if (g.open.load(std::memory_order_relaxed) != o) continue;
         g.slot_waiters++;
-        g.slot_cv.wait(lk);
+        g.slot_cv.wait_for(lk, std::chrono::microseconds(200));
         g.slot_waiters--;
     }
     if (!s) {
@@ -841,6 +853,20 @@ struct Parts {
 
 namespace {
 
+std::mutex g_parts_mu;
+std::vector<Parts*> g_live_parts;          // bodies that still hold a slot
+
+void parts_forget(Parts* p)
+{
+    std::lock_guard<std::mutex> lk(g_parts_mu);
+    for (size_t i = 0; i < g_live_parts.size(); ++i)
+        if (g_live_parts[i] == p) {
+            g_live_parts[i] = g_live_parts.back();
+            g_live_parts.pop_back();
+            return;
+        }
+}
+
 // p->mu held.  Waits for slices [landed_upto, upto) and hands the slot back once
 // the last one is in.
 bool parts_advance(Parts* p, uint32_t upto)
@@ -854,10 +880,40 @@ bool parts_advance(Parts* p, uint32_t upto)
         p->landed_upto++;
     }
     if (p->s && p->landed_upto == p->landed.size()) {
-        release_slot(p->s);
+        Slot* s = p->s;
         p->s = nullptr;
+        parts_forget(p);
+        release_slot(s);
     }
     return true;
+}
+
+bool reap_finished_parts()
+{
+    // candidates first, so that no body's lock is taken while the registry's is held
+    std::vector<Parts*> live;
+    {
+        std::lock_guard<std::mutex> lk(g_parts_mu);
+        live = g_live_parts;
+    }
+    bool any = false;
+    for (Parts* p : live) {
+        std::unique_lock<std::mutex> reg(g_parts_mu);            // p stays alive while it is registered
+        bool still = false;
+        for (Parts* q : g_live_parts) still |= q == p;
+        if (!still || !p->mu.try_lock()) continue;
+        reg.unlock();
+        if (p->s && !p->landed.empty() && hipEventQuery(p->landed.back()) == hipSuccess) {
+            // slices land out of order across the two copy streams: the last event alone does not say all are in
+            bool all = true;
+            for (size_t i = p->landed_upto; i < p->landed.size() && all; ++i) all = hipEventQuery(p->landed[i]) == hipSuccess;
+            if (all) any |= parts_advance(p, (uint32_t)p->landed.size());
+        } else {
+            (void)hipGetLastError();                             // hipErrorNotReady is not an error here
+        }
+        p->mu.unlock();
+    }
+    return any;
 }
 
 }  // namespace
@@ -915,6 +971,10 @@ Parts* parts_open(const oval_obj_desc& desc, std::string* err)
         return nullptr;
     }
     p->s = s;
+    {
+        std::lock_guard<std::mutex> lk(g_parts_mu);
+        g_live_parts.push_back(p);
+    }
     return p;
 }
 
@@ -946,6 +1006,8 @@ void parts_close(Parts* p)
             p->s = nullptr;
         }
     }
+    parts_forget(p);                                         // (a body that never gave its slot back is still listed)
+    { std::lock_guard<std::mutex> lk(p->mu); }               // a reaper that found it listed a moment ago is done with it
     for (hipEvent_t ev : p->landed)
         if (ev) (void)hipEventDestroy(ev);
     pool_give(p->buf);

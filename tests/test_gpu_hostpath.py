@@ -363,3 +363,37 @@ def test_every_host_path_at_once_while_batching_toggles(oracle):
         pattern.set_stream_chunk(32 << 20)
         pattern.set_clock(-1)
     assert not errors, errors[:5]
+
+
+def test_idle_generated_bodies_do_not_starve_other_callers(oracle):
+    """More multipart bodies open at once than the engine has staging slots, none
+    of them touched yet (uploads that have not started): further bodies and
+    micro-batched small calls still go through, because a body's slot is taken
+    back as soon as its last slice has landed, whoever notices."""
+    from oval_amd import pattern
+    from oval_amd.object import Object
+
+    pattern.init(0)
+    pattern.set_clock(T0)
+    held = []
+    try:
+        size = 3 << 20
+        for i in range(40):                                               # the engine has 18 slots
+            obj = Object("ov%010x" % i, size, i + 1)
+            held.append((obj, pattern.GenerateParts(size, 7, "test-bucket", obj, 1 << 20)))
+        pattern.set_batching(True, window_us=0)
+        small = Object("ov00000000ff", 4096, 3)
+        for _ in range(50):
+            assert pattern.Generate(4096, 7, "test-bucket", small) == oracle.generate(4096, 7, "test-bucket", small.Key, 3, T0)
+        pattern.set_batching(False)
+        big = Object("ov00000000fe", 1 << 20, 2)                          # takes a slot of its own
+        pattern.Valid(7, "test-bucket", big, pattern.Generate(1 << 20, 7, "test-bucket", big))
+        for obj, parts in held[::7]:
+            want = np.frombuffer(oracle.generate(size, 7, "test-bucket", obj.Key, obj.WriteCount, T0), np.uint8)
+            got = np.concatenate([parts.part(i) for i in range(len(parts))])
+            assert np.array_equal(got, want)
+    finally:
+        pattern.set_batching(False)
+        for _, parts in held:
+            parts.close()
+        pattern.set_clock(-1)
