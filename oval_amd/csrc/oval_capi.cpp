@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -377,6 +378,77 @@ int oval_desc_init(oval_obj_desc* d, const char* bucket, size_t bucket_len, cons
     return OVAL_OK;
 }
 
+// A few helper threads for host work that is too large for one core (staging
+// copies of pageable bodies, scanning and copying a million descriptors): tasks
+// 0 .. n-1 are handed out through a counter, the caller takes part, one run at
+// a time.  The threads are started on first use and sleep until the process ends.
+namespace {
+constexpr int kPoolHelpers = 7;          // + the calling thread
+
+class TaskPool {
+public:
+    static TaskPool& get()
+    {
+        static TaskPool* p = new TaskPool;   // never destroyed: its threads sleep until the process ends
+        return *p;
+    }
+
+    void run(size_t n, const std::function<void(size_t)>& fn)
+    {
+        if (n == 0) return;
+        if (n == 1) { fn(0); return; }
+        std::lock_guard<std::mutex> call(call_mu_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (threads_ == 0)
+                for (; threads_ < kPoolHelpers; ++threads_) std::thread([this] { worker(); }).detach();
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0, std::memory_order_relaxed);
+            pending_ = threads_;
+            ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+    }
+
+private:
+    void work()
+    {
+        for (;;) {
+            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n_) return;
+            (*fn_)(i);
+        }
+    }
+
+    void worker()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            lk.unlock();
+            work();
+            lk.lock();
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+
+    std::mutex call_mu_;                 // one run at a time
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    int threads_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_ = 0;
+    std::atomic<size_t> next_{0};
+};
+}  // namespace
+
 // true when the name certainly has no white space at either edge: both edge
 // bytes are ASCII and not space (a multi-byte white-space rune starts with a
 // byte >= 0xC2 and ends with one >= 0x80)
@@ -397,17 +469,27 @@ static inline uint16_t slow_flags_of(const oval_obj_desc& d)
     return f;
 }
 
-// Checks a descriptor set and computes its totals.  `fix` receives the indices
-// of the descriptors whose OVAL_DESC_*_SLOW bits differ from what their names
-// demand.
-static int scan_descs(const oval_obj_desc* descs, uint64_t n_obj, uint64_t* total_units_out,
-                      uint64_t* span_bytes_out, bool* no_fill_out, std::vector<uint64_t>* fix)
+// Checks descriptors [begin, end) of a set and computes their totals.  `fix`
+// receives the indices of the descriptors whose OVAL_DESC_*_SLOW bits differ
+// from what their names demand.
+struct ScanPart {
+    uint64_t begin = 0, end = 0;
+    uint64_t total_units = 0, last_end = 0;
+    bool no_fill = false;
+    std::vector<uint64_t> fix;
+    int rc = OVAL_OK;
+};
+
+static int scan_range(const oval_obj_desc* descs, ScanPart* part)
 {
     bool no_fill = false;
-    if (n_obj >= 0xFFFFFFF0ull) return fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
-    uint64_t prev_end = 0, total_units = 0;
+    // "the previous object" of the range's first one is the element before it
+    uint64_t prev_end = part->begin ? descs[part->begin - 1].body_offset +
+                                          (uint64_t)descs[part->begin - 1].n_units * OVAL_UNIT_SIZE : 0;
+    uint64_t total_units = 0;
     const uint16_t slow_bits = OVAL_DESC_BUCKET_SLOW | OVAL_DESC_KEY_SLOW;
-    for (uint64_t i = 0; i < n_obj; ++i) {
+    part->fix.clear();
+    for (uint64_t i = part->begin; i < part->end; ++i) {
         const oval_obj_desc& d = descs[i];
         if (d.body_offset % OVAL_UNIT_SIZE)
             return fail(OVAL_E_LAYOUT, "object %llu: body_offset %llu is not a multiple of 256",
@@ -421,14 +503,43 @@ static int scan_descs(const oval_obj_desc* descs, uint64_t n_obj, uint64_t* tota
         prev_end = d.body_offset + (uint64_t)d.n_units * OVAL_UNIT_SIZE;
         total_units += d.n_units;
         no_fill |= (d.flags & OVAL_DESC_NO_FILL) != 0;
-        if (fix && (d.flags & slow_bits) != slow_flags_of(d)) fix->push_back(i);
+        if ((d.flags & slow_bits) != slow_flags_of(d)) part->fix.push_back(i);
         if (prev_end / OVAL_UNIT_SIZE >= 0xFFFFFF00ull)
             return fail(OVAL_E_LAYOUT, "batch spans %llu bytes; the limit is just under 1 TiB",
                         (unsigned long long)prev_end);
     }
+    part->no_fill = no_fill;
+    part->total_units = total_units;
+    part->last_end = prev_end;
+    return OVAL_OK;
+}
+
+// The whole set; large ones in up to eight ranges side by side (a range only
+// needs the element before its first one).  The first failing range, in table
+// order, is scanned again on the calling thread, whose error text the caller reads.
+static int scan_descs(const oval_obj_desc* descs, uint64_t n_obj, uint64_t* total_units_out,
+                      uint64_t* span_bytes_out, bool* no_fill_out, std::vector<uint64_t>* fix)
+{
+    if (n_obj >= 0xFFFFFFF0ull) return fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
+    const uint64_t n_parts = n_obj >= (128u << 10) ? (n_obj >> 16 < 8 ? n_obj >> 16 : 8) : 1;
+    std::vector<ScanPart> parts(n_parts);
+    for (uint64_t p = 0; p < n_parts; ++p) {
+        parts[p].begin = n_obj * p / n_parts;
+        parts[p].end = n_obj * (p + 1) / n_parts;
+    }
+    TaskPool::get().run(n_parts, [&](size_t p) { parts[p].rc = scan_range(descs, &parts[p]); });
+    uint64_t total_units = 0;
+    bool no_fill = false;
+    fix->clear();
+    for (ScanPart& part : parts) {
+        if (part.rc) return n_parts == 1 ? part.rc : scan_range(descs, &part);
+        total_units += part.total_units;
+        no_fill |= part.no_fill;
+        fix->insert(fix->end(), part.fix.begin(), part.fix.end());
+    }
     *no_fill_out = no_fill;
     *total_units_out = total_units;
-    *span_bytes_out = prev_end;
+    *span_bytes_out = n_obj ? parts.back().last_end : 0;
     return OVAL_OK;
 }
 
@@ -674,7 +785,6 @@ constexpr uint64_t kTileBytes = (uint64_t)oval::kUnitsPerTile * OVAL_UNIT_SIZE;
 constexpr uint32_t kSliceTiles = 512;   // 32 MiB
 constexpr uint64_t kSliceBytes = kSliceTiles * kTileBytes;
 constexpr size_t kMaxRunsPerSlice = 64;  // more separate bodies than this in a slice: the slice round-trips instead
-constexpr int kCopyHelpers = 7;          // + the calling thread
 constexpr size_t kCopySegBytes = 1u << 20;
 
 struct CopySeg {
@@ -684,72 +794,16 @@ struct CopySeg {
 };
 
 // memcpy of a list of segments spread over a few threads; the caller takes part.
-class CopyPool {
-public:
-    static CopyPool& get()
-    {
-        static CopyPool* p = new CopyPool;   // never destroyed: its threads sleep until the process ends
-        return *p;
+void copy_segments(const CopySeg* segs, size_t n)
+{
+    size_t bytes = 0;
+    for (size_t i = 0; i < n; ++i) bytes += segs[i].n;
+    if (n <= 1 || bytes < (4u << 20)) {
+        for (size_t i = 0; i < n; ++i) std::memcpy(segs[i].dst, segs[i].src, segs[i].n);
+        return;
     }
-
-    void run(const CopySeg* segs, size_t n)
-    {
-        size_t bytes = 0;
-        for (size_t i = 0; i < n; ++i) bytes += segs[i].n;
-        if (n <= 1 || bytes < (4u << 20)) {
-            for (size_t i = 0; i < n; ++i) std::memcpy(segs[i].dst, segs[i].src, segs[i].n);
-            return;
-        }
-        std::lock_guard<std::mutex> call(call_mu_);
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            if (threads_ == 0)
-                for (; threads_ < kCopyHelpers; ++threads_) std::thread([this] { worker(); }).detach();
-            segs_ = segs;
-            n_segs_ = n;
-            next_.store(0, std::memory_order_relaxed);
-            pending_ = threads_;
-            ++gen_;
-        }
-        cv_.notify_all();
-        work();
-        std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [this] { return pending_ == 0; });
-    }
-
-private:
-    void work()
-    {
-        for (;;) {
-            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
-            if (i >= n_segs_) return;
-            std::memcpy(segs_[i].dst, segs_[i].src, segs_[i].n);
-        }
-    }
-
-    void worker()
-    {
-        uint64_t seen = 0;
-        std::unique_lock<std::mutex> lk(mu_);
-        for (;;) {
-            cv_.wait(lk, [&] { return gen_ != seen; });
-            seen = gen_;
-            lk.unlock();
-            work();
-            lk.lock();
-            if (--pending_ == 0) done_cv_.notify_one();
-        }
-    }
-
-    std::mutex call_mu_;                 // one parallel copy at a time
-    std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
-    int threads_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
-    const CopySeg* segs_ = nullptr;
-    size_t n_segs_ = 0;
-    std::atomic<size_t> next_{0};
-};
+    TaskPool::get().run(n, [segs](size_t i) { std::memcpy(segs[i].dst, segs[i].src, segs[i].n); });
+}
 
 void add_segs(std::vector<CopySeg>& out, char* dst, const char* src, uint64_t n)
 {
@@ -843,7 +897,7 @@ void oval_internal_parallel_copy(void* dst, const void* src, size_t n)
 {
     std::vector<CopySeg> segs;
     add_segs(segs, (char*)dst, (const char*)src, n);
-    CopyPool::get().run(segs.data(), segs.size());
+    copy_segments(segs.data(), segs.size());
 }
 
 uint32_t oval_internal_host_slices(uint64_t span_bytes)
@@ -884,7 +938,7 @@ int oval_internal_fill_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t 
     auto drain = [&](uint32_t k) {                              // pageable: bounce slot -> caller's memory
         Drain& d = drains[k % kSlots];
         hipError_t de = hipEventSynchronize(ctx->bounce_ev[k % kSlots]);
-        if (de == hipSuccess) CopyPool::get().run(d.segs.data(), d.segs.size());
+        if (de == hipSuccess) copy_segments(d.segs.data(), d.segs.size());
         return de;
     };
     uint32_t k = 0;
@@ -981,7 +1035,7 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
             if (ue != hipSuccess) return ue;
             segs.clear();
             add_segs(segs, bounce_slot(ctx, slot), src, b1 - b0);
-            CopyPool::get().run(segs.data(), segs.size());
+            copy_segments(segs.data(), segs.size());
             src = bounce_slot(ctx, slot);
         }
         // the slot's previous slice must have been validated
