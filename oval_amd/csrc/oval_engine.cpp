@@ -153,7 +153,9 @@ struct Pipeline {
     std::mutex ctl_mu;                    // serialises set_batching / shutdown (held across the joins)
 };
 
-Pipeline g;
+// Never destroyed: a process that exits while micro-batching is on still has lane threads asleep in
+// lane_loop, and destroying their std::thread objects (or the mutex they wait on) at exit would abort it.
+Pipeline& g = *new Pipeline;
 
 void pool_drop_all();                     // pinned buffers of the generated-parts pool (below)
 
@@ -694,7 +696,13 @@ void shutdown()
     std::unique_lock<std::mutex> lk(g.mu);
     // every slot must be home before its resources go
     g.slot_waiters++;
-    g.slot_cv.wait(lk, [] { return !g.inited || g.free_slots.size() == (size_t)kSlots; });
+    while (g.inited && g.free_slots.size() != (size_t)kSlots) {
+        lk.unlock();
+        (void)reap_finished_parts();                             // generated bodies nobody is reading any more
+        lk.lock();
+        if (!g.inited || g.free_slots.size() == (size_t)kSlots) break;
+        g.slot_cv.wait_for(lk, std::chrono::milliseconds(1));
+    }
     g.slot_waiters--;
     for (Slot& s : g.slots) destroy_slot(s);
     pool_drop_all();

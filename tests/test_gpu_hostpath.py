@@ -397,3 +397,49 @@ def test_idle_generated_bodies_do_not_starve_other_callers(oracle):
         for _, parts in held:
             parts.close()
         pattern.set_clock(-1)
+
+
+def test_shutdown_with_a_generated_body_still_open(oracle):
+    """Shutdown does not wait for a caller to finish reading a multipart body
+    whose bytes have all landed; the body stays readable (it lives in pinned host
+    memory), and the engine comes back with the next init."""
+    from oval_amd import pattern
+    from oval_amd.object import Object
+
+    pattern.init(0)
+    pattern.set_clock(T0)
+    try:
+        size = 5 << 20
+        obj = Object("ov00000000aa", size, 4)
+        parts = pattern.GenerateParts(size, 9, "test-bucket", obj, 1 << 20)
+        first = parts.part(0).copy()
+        pattern.shutdown()
+        want = np.frombuffer(oracle.generate(size, 9, "test-bucket", obj.Key, 4, T0), np.uint8)
+        assert np.array_equal(first, want[:1 << 20])
+        assert np.array_equal(parts.part(4), want[4 << 20:])
+        parts.close()
+        pattern.init(0)
+        assert pattern.Generate(512, 9, "test-bucket", obj) == oracle.generate(512, 9, "test-bucket", obj.Key, 4, T0)
+    finally:
+        pattern.init(0)
+        pattern.set_clock(-1)
+
+
+def test_process_exits_cleanly_with_micro_batching_still_on():
+    """A caller that never switches micro-batching off (a Go binary that just
+    returns from main) must not be aborted at exit by the lane threads it leaves
+    asleep."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from oval_amd import pattern\n"
+            "from oval_amd.object import Object\n"
+            "pattern.init(0)\n"
+            "pattern.set_batching(True)\n"
+            "b = pattern.Generate(4096, 1, 'b', Object('ov0000000001', 4096, 1))\n"
+            "print('generated', len(b))\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, (p.returncode, p.stderr[-1500:])
+    assert "generated 4096" in p.stdout
