@@ -240,6 +240,9 @@ def main():
     ap.add_argument("--verify-oracle", action="store_true",
                     help="rank 0 recomputes every rank's shard with the CPU oracle and requires the all-reduced "
                          "counters to equal the oracle's over the whole batch (small --objects only)")
+    ap.add_argument("--global-table", action="store_true",
+                    help="also exchange the job-wide first-bad-unit table (4 bytes per object of the whole job, "
+                         "minimum over ranks) after every validate: the optional second form of the collective")
     ap.add_argument("--verify-plan", action="store_true",
                     help="require the all-reduced counters to equal what the damage plans of all ranks imply "
                          "(no CPU pass over the bodies: works at full size)")
@@ -268,7 +271,7 @@ def main():
 
     from oval_amd import engine
     from oval_amd.batch import DeviceCorruption, expected_counters, plan_corruption, span_bytes, split_batches
-    from oval_amd.dist import all_reduce, all_reduce_counters
+    from oval_amd.dist import all_reduce, all_reduce_counters, all_reduce_first_bad
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -329,8 +332,22 @@ def main():
         damage = [DeviceCorruption(p, pl, body.device) for p, pl in zip(parts, plans)]
         planned = sum(expected_counters(p, pl) for p, pl in zip(parts, plans))
 
+    table = my_table = None
+    if args.global_table:
+        # where this rank's objects sit in the table of the whole job: ranks in order
+        counts = [n_obj]
+        if dist:
+            counts = [None] * world
+            dist.all_gather_object(counts, n_obj)
+        base = sum(counts[:rank])
+        table = torch.empty(sum(counts), dtype=torch.int32, device=body.device)
+        offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])])
+        my_table = [table[base + int(offs[k]): base + int(offs[k + 1])] for k in range(len(parts))]
+
     def step(timers=None):
         counters.zero_()
+        if table is not None:
+            table.fill_(-1)                    # 0xFFFFFFFF everywhere: no bad unit known
         for k, layout in enumerate(layouts):
             tf, tv = timers[k] if timers else (None, None)
             if tf: tf.start()
@@ -340,10 +357,16 @@ def main():
             if tv: tv.start()
             layout.validate(body, results[k], counters)
             if tv: tv.stop()
+            if table is not None:
+                engine.gather_first_bad(ctx, results[k], len(parts[k]), my_table[k])
         if comm:                               # the one collective of a batch
             comm.all_reduce_counters(counters)
+            if table is not None and world > 1:
+                comm.all_reduce_first_bad(table)
         else:
             all_reduce_counters(counters)
+            if table is not None:
+                all_reduce_first_bad(table)
 
     for _ in range(args.warmup):
         step()
@@ -403,6 +426,20 @@ def main():
                 expect += O.validate_batch(p.view(O.DESC_DTYPE), host)[1]
         assert np.array_equal(tot.astype(np.uint64), expect), f"counters {tot} differ from the oracle's {expect}"
         verified = [int(x) for x in expect]
+        if table is not None:
+            # the whole job's first bad units, rank after rank, from the oracle
+            want = []
+            for r in range(world):
+                d_r, _ = build_batch(args.workload, r, world, args.sharding, args.objects, args.seed, size_override)
+                for k, p in enumerate(split_batches(d_r, int(args.batch_gib * (1 << 30)))):
+                    host = np.zeros(span_bytes(p), dtype=np.uint8)
+                    O.fill_batch(p.view(O.DESC_DTYPE), host)
+                    if args.corrupt > 0:
+                        apply_corruption_numpy(host, p, plan_corruption(p, args.corrupt, seed=args.seed * 1000003 + r * 1009 + k))
+                    want.append(O.validate_batch(p.view(O.DESC_DTYPE), host)[0]["first_bad_unit"])
+            want = np.concatenate(want)
+            got = table.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, want), "the job-wide first-bad-unit table differs from the oracle's"
 
     if rank == 0:
         ms_per_step = wall / args.steps * 1e3
@@ -468,6 +505,11 @@ def main():
             out["counters_equal_oracle"] = True
         if plan_ok:
             out["counters_equal_plan"] = True
+        if table is not None:
+            out["config"]["global_table_objects"] = int(table.numel())
+            if verified is not None:
+                out["global_table_equals_oracle"] = True
+            out["global_table_bad_objects"] = int((table != -1).sum().item())
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(descs, args.cpu_seconds)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -265,6 +265,16 @@ int oval_comm_destroy(oval_comm* comm);
  * context's stream (ncclAllReduce, ncclUint64, ncclSum). */
 int oval_allreduce_counters(oval_ctx* ctx, oval_comm* comm, uint64_t* counters_dev, size_t n);
 
+/* Optional second form of the exchange: the first-bad-unit table of the WHOLE job
+ * on every rank (4 bytes per object: 40 MB at 10 M objects).  Each rank fills a
+ * table of the job's object count with 0xFF bytes (OVAL_NO_BAD_UNIT), writes its
+ * own objects' first_bad_unit at its own place with oval_gather_first_bad
+ * (table_dev points at that place: table_dev[i] = results_dev[i].first_bad_unit),
+ * and the minimum over ranks (ncclAllReduce, ncclUint32, ncclMin) leaves every
+ * rank with the table of all objects.  Both asynchronous on the context's stream. */
+int oval_gather_first_bad(oval_ctx* ctx, const oval_obj_result* results_dev, uint64_t n_obj, uint32_t* table_dev);
+int oval_allreduce_first_bad(oval_ctx* ctx, oval_comm* comm, uint32_t* table_dev, size_t n);
+
 /* ---- kernel launch tuning (benchmarks only) ------------------------------
  * Workgroup sizes of the fill and the validate kernel: 128, 256, 512 or 1024
  * threads; 0 restores the default (256, the fastest measured for both). */

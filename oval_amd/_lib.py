@@ -90,6 +90,8 @@ SIGNATURES = {
     "oval_comm_create": (_int, [_vp, _int, _int, _vp, _pp]),
     "oval_comm_destroy": (_int, [_vp]),
     "oval_allreduce_counters": (_int, [_vp, _vp, _vp, _sz]),
+    "oval_gather_first_bad": (_int, [_vp, _vp, _u64, _vp]),
+    "oval_allreduce_first_bad": (_int, [_vp, _vp, _vp, _sz]),
     "oval_timer_create": (_int, [_vp, _pp]),
     "oval_timer_destroy": (_int, [_vp]),
     "oval_timer_start": (_int, [_vp, _vp]),

@@ -16,6 +16,7 @@
 
 #include "../../include/oval_hip.h"
 #include "oval_capi_internal.h"
+#include "oval_kernels.h"
 
 struct oval_comm {
     ncclComm_t comm = nullptr;
@@ -127,6 +128,30 @@ int oval_allreduce_counters(oval_ctx* ctx, oval_comm* comm, uint64_t* counters_d
         return oval_internal_fail(OVAL_E_INVALID, "the communicator was created on device %d, the context runs on %d",
                                   comm->device, oval_internal_ctx_device(ctx));
     const ncclResult_t e = rccl().AllReduce(counters_dev, counters_dev, n, ncclUint64, ncclSum, comm->comm,
+                                            oval_internal_ctx_stream(ctx));
+    return e == ncclSuccess ? OVAL_OK : rccl_fail("ncclAllReduce", e);
+}
+
+int oval_gather_first_bad(oval_ctx* ctx, const oval_obj_result* results_dev, uint64_t n_obj, uint32_t* table_dev)
+{
+    if (!ctx || (n_obj && (!results_dev || !table_dev))) return oval_internal_fail(OVAL_E_INVALID, "NULL argument");
+    if (n_obj >= 0xFFFFFFF0ull) return oval_internal_fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
+    if (((uintptr_t)results_dev) % 16 || ((uintptr_t)table_dev) % 4)
+        return oval_internal_fail(OVAL_E_INVALID, "results_dev must be 16-byte aligned, table_dev 4-byte aligned");
+    const hipError_t e = oval::launch_gather_first_bad(oval_internal_ctx_stream(ctx), results_dev, (uint32_t)n_obj, table_dev);
+    if (e != hipSuccess) return oval_internal_fail(OVAL_E_HIP, "gather_first_bad: %s", hipGetErrorString(e));
+    return OVAL_OK;
+}
+
+int oval_allreduce_first_bad(oval_ctx* ctx, oval_comm* comm, uint32_t* table_dev, size_t n)
+{
+    if (!ctx || !comm || (!table_dev && n)) return oval_internal_fail(OVAL_E_INVALID, "NULL argument");
+    if (((uintptr_t)table_dev) % 4) return oval_internal_fail(OVAL_E_INVALID, "table_dev is not 4-byte aligned");
+    if (n == 0) return OVAL_OK;
+    if (oval_internal_ctx_device(ctx) != comm->device)
+        return oval_internal_fail(OVAL_E_INVALID, "the communicator was created on device %d, the context runs on %d",
+                                  comm->device, oval_internal_ctx_device(ctx));
+    const ncclResult_t e = rccl().AllReduce(table_dev, table_dev, n, ncclUint32, ncclMin, comm->comm,
                                             oval_internal_ctx_stream(ctx));
     return e == ncclSuccess ? OVAL_OK : rccl_fail("ncclAllReduce", e);
 }

@@ -54,6 +54,8 @@ hipError_t launch_fill(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv
                        uint32_t tile_begin, uint32_t tile_end);
 hipError_t launch_init_results(hipStream_t s, const LayoutView& lv, oval_obj_result* results,
                                unsigned long long* counters);
+// table[i] = results[i].first_bad_unit for i < n_obj
+hipError_t launch_gather_first_bad(hipStream_t s, const oval_obj_result* results, uint32_t n_obj, uint32_t* table);
 hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv,
                            const void* body, uint32_t tile_begin, uint32_t tile_end,
                            oval_obj_result* results, unsigned long long* counters,

@@ -591,6 +591,14 @@ __global__ __launch_bounds__(256) void init_results_kernel(u32x4* __restrict__ r
     }
 }
 
+// table[i] = results[i].first_bad_unit: one rank's slice of the job-wide first-bad-unit table
+__global__ __launch_bounds__(256) void gather_first_bad_kernel(const u32x4* __restrict__ results, uint32_t n_obj,
+                                                               uint32_t* __restrict__ table)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_obj; i += stride) table[i] = results[i].y;
+}
+
 // The same for a caller that does not know the sum of n_units: it is taken
 // from the descriptor table here (one atomicAdd per wavefront).
 __global__ __launch_bounds__(256) void init_results_sum_kernel(u32x4* __restrict__ results,
@@ -718,6 +726,15 @@ hipError_t launch_init_results(hipStream_t s, const LayoutView& lv, oval_obj_res
     if (blocks == 0u) blocks = 1u;
     init_results_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<u32x4*>(results), lv.n_obj, counters,
                                                (unsigned long long)lv.total_units);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_first_bad(hipStream_t s, const oval_obj_result* results, uint32_t n_obj, uint32_t* table)
+{
+    if (n_obj == 0) return hipSuccess;
+    uint32_t blocks = (n_obj + 255u) / 256u;
+    if (blocks > 2048u) blocks = 2048u;
+    gather_first_bad_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const u32x4*>(results), n_obj, table);
     return hipGetLastError();
 }
 

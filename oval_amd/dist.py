@@ -53,3 +53,21 @@ def all_reduce_counters(counters):
     """Sums the (12,) int64 counter vector over all ranks, in place: the single
     collective of a batch."""
     return all_reduce(counters)
+
+
+def all_reduce_first_bad(table):
+    """The optional second form of the exchange: `table` holds one uint32 first-bad
+    unit per object of the WHOLE job (0xFFFFFFFF = none; this rank's objects filled
+    in, everything else none), as an int32 tensor; the minimum over all ranks, in
+    place, gives every rank the table of all objects.  torch has no unsigned
+    minimum, so the sign bit is flipped around the reduction (unsigned order =
+    signed order of the flipped values)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return table
+    flipped = table ^ torch.iinfo(torch.int32).min
+    all_reduce(flipped, dist.ReduceOp.MIN)
+    table.copy_(flipped ^ torch.iinfo(torch.int32).min)
+    return table

@@ -178,6 +178,13 @@ def results_to_numpy(results, n_obj: int) -> np.ndarray:
     return out
 
 
+def gather_first_bad(ctx: "Context", results, n_obj: int, table_slice) -> None:
+    """table_slice[i] = first_bad_unit of results[i] (uint32 in an int32 CUDA tensor), on the context's stream."""
+    if table_slice.numel() < n_obj:
+        raise ValueError("table slice shorter than the result array")
+    check(_lib.lib().oval_gather_first_bad(ctx.handle, results.data_ptr(), n_obj, table_slice.data_ptr()))
+
+
 class Comm:
     """RCCL communicator behind oval_allreduce_counters: one rank per GPU, the
     batch counters are the only thing summed over ranks."""
@@ -198,6 +205,11 @@ class Comm:
     def all_reduce_counters(self, counters) -> None:
         """counters: int64 CUDA tensor, summed over all ranks in place on the context's stream."""
         check(_lib.lib().oval_allreduce_counters(self.ctx.handle, self._h, counters.data_ptr(), counters.numel()))
+
+    def all_reduce_first_bad(self, table) -> None:
+        """table: int32 CUDA tensor holding uint32 first-bad units (0xFFFFFFFF = none), one per object of
+        the whole job; the minimum over all ranks, in place on the context's stream."""
+        check(_lib.lib().oval_allreduce_first_bad(self.ctx.handle, self._h, table.data_ptr(), table.numel()))
 
     def close(self) -> None:
         if self._h:

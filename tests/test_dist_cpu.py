@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oval_amd.batch import WorkerSpace, apply_corruption_numpy, plan_corruption, span_bytes, synthetic_batch
-from oval_amd.dist import all_reduce_counters, shard_batch
+from oval_amd.dist import all_reduce_counters, all_reduce_first_bad, shard_batch
 
 T0 = 1709558129112997
 SPACE = dict(num_obj=768, num_worker=6, runner_id=1, start_worker_id=0xFFFD)
@@ -23,6 +23,17 @@ def _free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def _shard_results(rank, world):
+    from oracle import oracle as O
+
+    sp = WorkerSpace(**SPACE)
+    d = shard_batch(sp, world, rank, "test-bucket", 4096, 16384, seed=7, unix_micro=T0)
+    body = np.zeros(span_bytes(d), dtype=np.uint8)
+    O.fill_batch(d.view(O.DESC_DTYPE), body)
+    apply_corruption_numpy(body, d, plan_corruption(d, 1e-3, seed=100 + rank))
+    return O.validate_batch(d.view(O.DESC_DTYPE), body)[0]["first_bad_unit"]
 
 
 def _shard_counters(rank, world):
@@ -45,6 +56,12 @@ def _worker(rank, world, port, out_dir):
     all_reduce_counters(t)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), t.numpy())
     np.save(os.path.join(out_dir, f"k{rank}.npy"), d["key"])
+    # the optional second form: the first-bad-unit table of the whole job on every rank
+    per = SPACE["num_obj"] // world
+    table = torch.full((SPACE["num_obj"],), -1, dtype=torch.int32)
+    table[rank * per:(rank + 1) * per] = torch.from_numpy(_shard_results(rank, world).view(np.int32))
+    all_reduce_first_bad(table)
+    np.save(os.path.join(out_dir, f"t{rank}.npy"), table.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,6 +75,10 @@ def test_two_ranks_sum_to_the_whole(tmp_path):
     expect = sum(_shard_counters(r, world)[1].astype(np.int64) for r in range(world))
     assert (got[0] == expect).all()
     assert got[0][0] == SPACE["num_obj"] and got[0][1] > 0 and got[0][3] >= got[0][1]
+    tables = [np.load(tmp_path / f"t{r}.npy").view(np.uint32) for r in range(world)]
+    whole_table = np.concatenate([_shard_results(r, world) for r in range(world)])
+    assert (tables[0] == whole_table).all() and (tables[1] == whole_table).all()
+    assert (whole_table != 0xFFFFFFFF).sum() == got[0][1]
     # the shards are disjoint and cover every key of the run
     keys = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])
     whole = synthetic_batch(WorkerSpace(**SPACE), range(SPACE["num_worker"]), "test-bucket", 4096, 16384, 7, T0)

@@ -64,8 +64,13 @@ def test_two_rank_rehearsal_with_damage_counters_equal_the_oracle(sharding):
                    "--master-addr", "127.0.0.1", "--master-port", port, "bench.py", "--gpus", "2",
                    "--backend", "gloo", "--objects", "30000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
                    "--workload", "cfg5", "--sizes", "4096-262144", "--corrupt", "1e-4", "--verify-oracle",
-                   "--sharding", sharding])
+                   "--sharding", sharding, "--global-table"])
     assert d["counters_equal_oracle"] is True
+    # the optional second form of the exchange: every rank ends up with the first bad unit of every object
+    # of the job (minimum over ranks of tables that each hold one rank's share)
+    assert d["global_table_equals_oracle"] is True
+    assert d["config"]["global_table_objects"] == 2 * d["config"]["objects_per_gpu"]
+    assert d["global_table_bad_objects"] == d["counters"][1]
     c = d["counters"]
     assert c[0] == 2 * d["config"]["objects_per_gpu"] and c[1] > 0 and c[3] >= c[1] and c[9] >= c[3]
     if sharding == "workers":
