@@ -39,8 +39,12 @@ def test_single_rank_line():
     # HBM traffic of the dominant kernel, measured by a child PMC run of the same command: within a few
     # per cent of the algorithmic bytes (descriptor and table reads on top of the bodies)
     r = d["roofline"]
-    assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
-    assert 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.15
+    if r["traffic_source"].startswith("measured in this run"):
+        assert 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.15
+    else:
+        # no profiler on this box (or this test itself runs under one): the line must say why, and must
+        # not pass a number off as measured (a non-default shape has no stored PMC pass to fall back to)
+        assert r["traffic"] is None and len(r["traffic_source"]) > 8, r["traffic_source"]
 
 
 def test_two_rank_rehearsal_sums_units_over_ranks():
