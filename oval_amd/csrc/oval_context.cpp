@@ -2,6 +2,11 @@
 // format) and descriptor tables built from a context.  See oval_context.hpp.
 #include "oval_context.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -38,6 +43,32 @@ int64_t rand_intn(int64_t n)
     uint64_t x;
     do x = splitmix64(); while (x > limit);
     return (int64_t)(x % un);
+}
+
+// Tasks 0 .. n-1 on up to eight host threads (the caller is one of them); `weight`
+// is the number of objects the tasks cover together: a thread per ~50 K of them.
+// A saved context of a million objects is 58 MB of JSON: built, written and read
+// on one core it costs more than validating every body it names on the device.
+template <class Fn>
+void parallel_tasks(size_t n, size_t weight, const Fn& fn)
+{
+    size_t n_threads = weight / 50000;
+    const size_t hw = std::thread::hardware_concurrency();
+    if (n_threads > 8) n_threads = 8;
+    if (hw && n_threads > hw) n_threads = hw;
+    if (n_threads > n) n_threads = n;
+    if (n_threads <= 1) {
+        for (size_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(i);
+    };
+    std::vector<std::thread> ts;
+    for (size_t t = 1; t < n_threads; ++t) ts.emplace_back(work);
+    work();
+    for (std::thread& t : ts) t.join();
 }
 
 }  // namespace
@@ -517,6 +548,49 @@ bool read_worker(Reader& r, Worker& w)
     });
 }
 
+// The workers array of a large saved context, its elements read side by side.
+// encoding/json writes every worker as `{"bucketsWithObject":[...]}` with no
+// white space, and a quote inside a JSON string is always escaped, so those
+// opening bytes can only occur where an object with that first key begins.  Each
+// occurrence is taken as the start of one element and the text up to the next
+// one is read as exactly one worker followed by a comma.  Anything that does not
+// fit (white space, other key order, such an object nested somewhere else, a
+// syntax error) makes this return false with nothing consumed, and the caller
+// reads the array in order, element by element, as it would have anyway.
+bool read_workers_side_by_side(Reader& r, std::vector<Worker>& out)
+{
+    static const char kOpen[] = "{\"bucketsWithObject\":[";
+    const size_t kOpenLen = sizeof kOpen - 1;
+    r.ws();
+    const char* const p0 = r.p;
+    if ((size_t)(r.end - p0) < (4u << 20) || *p0 != '[') return false;
+    std::vector<const char*> starts;
+    for (const char* q = p0 + 1; q < r.end;) {
+        const char* f = static_cast<const char*>(memmem(q, (size_t)(r.end - q), kOpen, kOpenLen));
+        if (!f) break;
+        if (f[-1] != (starts.empty() ? '[' : ',')) return false;
+        starts.push_back(f);
+        q = f + kOpenLen;
+    }
+    if (starts.size() < 2 || starts[0] != p0 + 1) return false;
+    const size_t n = starts.size();
+    std::vector<Worker> workers(n);
+    std::vector<const char*> stop(n, nullptr);
+    std::atomic<bool> ok{true};
+    parallel_tasks(n, (size_t)(r.end - p0) / 56, [&](size_t i) {
+        if (!ok.load(std::memory_order_relaxed)) return;
+        // all but the last element end where the comma before the next one stands
+        Reader part{starts[i], i + 1 < n ? starts[i + 1] - 1 : r.end, r.begin, std::string()};
+        if (!read_worker(part, workers[i]) || (i + 1 < n && part.p != part.end)) ok.store(false, std::memory_order_relaxed);
+        stop[i] = part.p;
+    });
+    if (!ok.load()) return false;
+    r.p = stop[n - 1];
+    if (!r.lit(']')) { r.p = p0; return false; }
+    out = std::move(workers);
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // JSON output: encoding/json's compact form with its default HTML escaping
 // ---------------------------------------------------------------------------
@@ -555,14 +629,108 @@ void put_string(std::string& out, const std::string& s)
     out.push_back('"');
 }
 
-void put_int(std::string& out, int64_t v) { out += std::to_string(v); }
+// decimal digits of v at q; returns the end
+char* put_digits(char* q, int64_t v)
+{
+    uint64_t u = v < 0 ? 0u - (uint64_t)v : (uint64_t)v;
+    if (v < 0) *q++ = '-';
+    char tmp[20];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + u % 10u); u /= 10u; } while (u);
+    while (n) *q++ = tmp[--n];
+    return q;
+}
+
+void put_int(std::string& out, int64_t v)
+{
+    char buf[24];
+    out.append(buf, (size_t)(put_digits(buf, v) - buf));
+}
+
+// true when put_string would copy s unchanged between its quotes
+bool plain_text(const std::string& s)
+{
+    for (const char ch : s) {
+        const unsigned char c = (unsigned char)ch;
+        if (c < 0x20 || c >= 0x80 || c == '"' || c == '\\' || c == '<' || c == '>' || c == '&') return false;
+    }
+    return true;
+}
+
+// `{"key":"...","size":N,"writeCount":N}`: the bulk of a saved context, assembled in one go
+void put_object_entry(std::string& out, const object::Object& o)
+{
+    if (o.Key.size() > 64 || !plain_text(o.Key)) {
+        out += "{\"key\":";
+        put_string(out, o.Key);
+        out += ",\"size\":"; put_int(out, o.Size);
+        out += ",\"writeCount\":"; put_int(out, o.WriteCount);
+        out.push_back('}');
+        return;
+    }
+    char buf[8 + 64 + 9 + 21 + 15 + 21 + 1];
+    char* q = buf;
+    std::memcpy(q, "{\"key\":\"", 8); q += 8;
+    std::memcpy(q, o.Key.data(), o.Key.size()); q += o.Key.size();
+    std::memcpy(q, "\",\"size\":", 9); q += 9;
+    q = put_digits(q, o.Size);
+    std::memcpy(q, ",\"writeCount\":", 14); q += 14;
+    q = put_digits(q, o.WriteCount);
+    *q++ = '}';
+    out.append(buf, (size_t)(q - buf));
+}
+
+size_t total_objects(const ExecutionContext& ec)
+{
+    size_t n = 0;
+    for (const Worker& w : ec.Workers)
+        for (const BucketWithObject& b : w.BucketsWithObject) n += b.ObjectMeta.ObjectList.size();
+    return n;
+}
+
+void marshal_worker(std::string& o, const Worker& wk)
+{
+    size_t objects = 0, ids = 0;
+    for (const BucketWithObject& bo : wk.BucketsWithObject) {
+        objects += bo.ObjectMeta.ObjectList.size();
+        ids += bo.ObjectMeta.ExistingObjectIDs.size();
+    }
+    o.reserve(256 + objects * 56 + ids * 8);
+    o += "{\"bucketsWithObject\":[";
+    for (size_t b = 0; b < wk.BucketsWithObject.size(); ++b) {
+        if (b) o.push_back(',');
+        const BucketWithObject& bo = wk.BucketsWithObject[b];
+        o += "{\"bucketName\":";
+        put_string(o, bo.BucketName);
+        o += ",\"objectMeta\":{\"objectList\":[";
+        const object::ObjectMeta& om = bo.ObjectMeta;
+        for (size_t i = 0; i < om.ObjectList.size(); ++i) {
+            if (i) o.push_back(',');
+            put_object_entry(o, om.ObjectList[i]);
+        }
+        o += "],\"existingObjectIDs\":[";
+        for (size_t i = 0; i < om.ExistingObjectIDs.size(); ++i) {
+            if (i) o.push_back(',');
+            put_int(o, om.ExistingObjectIDs[i]);
+        }
+        o += "],\"keyIDOffset\":"; put_int(o, om.KeyIDOffset);
+        o += ",\"KeyPrefix\":";
+        put_string(o, om.KeyPrefix);
+        o += "}}";
+    }
+    o += "]}";
+}
 
 }  // namespace
 
-std::string MarshalContext(const ExecutionContext& ec)
+namespace {
+
+// The text of a context in pieces, in order: everything up to and including the
+// opening bracket of the workers array, one piece per worker (commas between
+// them are the writer's business), and the closing "]}".
+void marshal_pieces(const ExecutionContext& ec, std::string& head, std::vector<std::string>& workers)
 {
-    std::string o;
-    o.reserve(256 + (size_t)CountExisting(ec) * 8);
+    std::string& o = head;
     o += "{\"endpoint\":";
     put_string(o, ec.Endpoint);
     o += ",\"bucketNames\":";
@@ -581,36 +749,25 @@ std::string MarshalContext(const ExecutionContext& ec)
     o += ",\"maxSize\":"; put_int(o, ec.MaxSize);
     o += ",\"startWorkerID\":"; put_int(o, ec.StartWorkerID);
     o += ",\"workers\":[";
-    for (size_t w = 0; w < ec.Workers.size(); ++w) {
+    // every worker's text on its own, side by side
+    workers.assign(ec.Workers.size(), std::string());
+    parallel_tasks(ec.Workers.size(), total_objects(ec), [&](size_t w) { marshal_worker(workers[w], ec.Workers[w]); });
+}
+
+}  // namespace
+
+std::string MarshalContext(const ExecutionContext& ec)
+{
+    std::string o;
+    std::vector<std::string> parts;
+    marshal_pieces(ec, o, parts);
+    size_t bytes = o.size() + 2;
+    for (const std::string& part : parts) bytes += part.size() + 1;
+    o.reserve(bytes);
+    for (size_t w = 0; w < parts.size(); ++w) {
         if (w) o.push_back(',');
-        o += "{\"bucketsWithObject\":[";
-        const Worker& wk = ec.Workers[w];
-        for (size_t b = 0; b < wk.BucketsWithObject.size(); ++b) {
-            if (b) o.push_back(',');
-            const BucketWithObject& bo = wk.BucketsWithObject[b];
-            o += "{\"bucketName\":";
-            put_string(o, bo.BucketName);
-            o += ",\"objectMeta\":{\"objectList\":[";
-            const object::ObjectMeta& om = bo.ObjectMeta;
-            for (size_t i = 0; i < om.ObjectList.size(); ++i) {
-                if (i) o.push_back(',');
-                o += "{\"key\":";
-                put_string(o, om.ObjectList[i].Key);
-                o += ",\"size\":"; put_int(o, om.ObjectList[i].Size);
-                o += ",\"writeCount\":"; put_int(o, om.ObjectList[i].WriteCount);
-                o.push_back('}');
-            }
-            o += "],\"existingObjectIDs\":[";
-            for (size_t i = 0; i < om.ExistingObjectIDs.size(); ++i) {
-                if (i) o.push_back(',');
-                put_int(o, om.ExistingObjectIDs[i]);
-            }
-            o += "],\"keyIDOffset\":"; put_int(o, om.KeyIDOffset);
-            o += ",\"KeyPrefix\":";
-            put_string(o, om.KeyPrefix);
-            o += "}}";
-        }
-        o += "]}";
+        o += parts[w];
+        std::string().swap(parts[w]);
     }
     o += "]}";
     return o;
@@ -620,16 +777,26 @@ Error SaveContext(const ExecutionContext& ec, const std::string& path)
 {
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) return Error::New("open " + path + ": " + std::strerror(errno));
-    const std::string data = MarshalContext(ec);
-    size_t off = 0;
-    while (off < data.size()) {
-        const size_t n = std::fwrite(data.data() + off, 1, data.size() - off, f);
-        if (n == 0) {
-            const std::string m = std::strerror(errno);
-            std::fclose(f);
-            return Error::New("write " + path + ": " + m);
+    std::string head;
+    std::vector<std::string> parts;
+    marshal_pieces(ec, head, parts);
+    // the pieces go to the file as they are: no second copy of the whole text
+    auto put = [&](const char* p, size_t n) {
+        while (n) {
+            const size_t w = std::fwrite(p, 1, n, f);
+            if (w == 0) return false;
+            p += w;
+            n -= w;
         }
-        off += n;
+        return true;
+    };
+    bool ok = put(head.data(), head.size());
+    for (size_t w = 0; ok && w < parts.size(); ++w) ok = (w == 0 || put(",", 1)) && put(parts[w].data(), parts[w].size());
+    ok = ok && put("]}", 2);
+    if (!ok) {
+        const std::string m = std::strerror(errno);
+        std::fclose(f);
+        return Error::New("write " + path + ": " + m);
     }
     if (std::fclose(f) != 0) return Error::New("close " + path + ": " + std::strerror(errno));
     return Error::Nil();
@@ -673,6 +840,7 @@ std::pair<ExecutionContext, Error> LoadSavedContext(const char* json, size_t len
             if (key_is(k, "startWorkerID")) return read_int_field(r, ec.StartWorkerID, "ExecutionContext.startWorkerID");
             if (key_is(k, "workers")) {
                 ec.Workers.clear();
+                if (read_workers_side_by_side(r, ec.Workers)) return true;
                 return read_array(r, [&] {
                     ec.Workers.emplace_back();
                     return read_worker(r, ec.Workers.back());
@@ -689,25 +857,46 @@ std::pair<ExecutionContext, Error> LoadSavedContext(const char* json, size_t len
     }
     if (ec.BucketNames.empty()) return {ExecutionContext(), Error::New("bucket list is empty.")};   // runner.go:54-57
     stamp_workers(ec);
-    for (Worker& w : ec.Workers)
-        for (BucketWithObject& b : w.BucketsWithObject) {
-            Error e = b.ObjectMeta.TidyUp();
-            if (!e.nil()) return {ExecutionContext(), e};
+    std::vector<Error> tidy(ec.Workers.size(), Error::Nil());
+    parallel_tasks(ec.Workers.size(), total_objects(ec), [&](size_t w) {
+        for (BucketWithObject& b : ec.Workers[w].BucketsWithObject) {
+            tidy[w] = b.ObjectMeta.TidyUp();
+            if (!tidy[w].nil()) return;
         }
+    });
+    for (const Error& e : tidy)
+        if (!e.nil()) return {ExecutionContext(), e};                // the first in table order
     return {std::move(ec), Error::Nil()};
 }
 
 std::pair<ExecutionContext, Error> LoadSavedContextFile(const std::string& path)
 {
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) return {ExecutionContext(), Error::New("open " + path + ": " + std::strerror(errno))};
+    const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return {ExecutionContext(), Error::New("open " + path + ": " + std::strerror(errno))};
+    // A regular file is read where the page cache holds it (no copy of tens of
+    // megabytes first); anything else (a pipe, an empty file) through read().
+    struct stat st;
+    if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        if (m != MAP_FAILED) {
+            ::close(fd);
+            auto out = LoadSavedContext(static_cast<const char*>(m), (size_t)st.st_size);
+            ::munmap(m, (size_t)st.st_size);
+            return out;
+        }
+    }
     std::string data;
     char buf[1 << 16];
-    size_t n;
-    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, n);
-    const bool bad = std::ferror(f) != 0;
-    std::fclose(f);
-    if (bad) return {ExecutionContext(), Error::New("read " + path + ": " + std::strerror(errno))};
+    for (;;) {
+        const ssize_t n = ::read(fd, buf, sizeof buf);
+        if (n > 0) { data.append(buf, (size_t)n); continue; }
+        if (n == 0) break;
+        if (errno == EINTR) continue;
+        const std::string m = std::strerror(errno);
+        ::close(fd);
+        return {ExecutionContext(), Error::New("read " + path + ": " + m)};
+    }
+    ::close(fd);
     return LoadSavedContext(data.data(), data.size());
 }
 
@@ -729,16 +918,17 @@ std::pair<ExecutionContext, Error> NewExecutionContext(const std::string& endpoi
     ec.StartWorkerID = startWorkerID >= 0 ? startWorkerID : rand_intn(maxWorkerID);
     ec.Workers.resize((size_t)numWorker);
     stamp_workers(ec);
-    for (int64_t i = 0; i < numWorker; ++i) {
-        Worker& w = ec.Workers[(size_t)i];
+    // workers own disjoint key ranges (runner.go:117-125): their object lists are built side by side
+    parallel_tasks((size_t)numWorker, (size_t)numObj * bucketNames.size(), [&](size_t i) {
+        Worker& w = ec.Workers[i];
         w.BucketsWithObject.reserve(bucketNames.size());
         for (const std::string& name : bucketNames) {
             w.BucketsWithObject.emplace_back();
             w.BucketsWithObject.back().BucketName = name;
             w.BucketsWithObject.back().ObjectMeta =
-                object::ObjectMeta(numObj / numWorker, (runnerID << 32) + (i << 24));
+                object::ObjectMeta(numObj / numWorker, (runnerID << 32) + ((int64_t)i << 24));
         }
-    }
+    });
     return {std::move(ec), Error::Nil()};
 }
 
@@ -797,23 +987,7 @@ struct Segment {
 template <class Fn>
 void for_each_segment(std::vector<Segment>& segs, size_t n_objects, const Fn& fn)
 {
-    size_t n_threads = n_objects / 50000;                      // a thread per ~50 K objects ...
-    const size_t hw = std::thread::hardware_concurrency();
-    if (n_threads > 8) n_threads = 8;                          // ... at most eight, at most one per core
-    if (hw && n_threads > hw) n_threads = hw;
-    if (n_threads > segs.size()) n_threads = segs.size();
-    if (n_threads <= 1) {
-        for (Segment& s : segs) fn(s);
-        return;
-    }
-    std::atomic<size_t> next{0};
-    auto work = [&] {
-        for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < segs.size();) fn(segs[i]);
-    };
-    std::vector<std::thread> ts;
-    for (size_t t = 1; t < n_threads; ++t) ts.emplace_back(work);
-    work();
-    for (std::thread& t : ts) t.join();
+    parallel_tasks(segs.size(), n_objects, [&](size_t i) { fn(segs[i]); });
 }
 
 }  // namespace

@@ -361,3 +361,59 @@ def test_object_entries_in_any_shape_load_alike():
                 '{"key":"k","size":1e3,"writeCount":1}'):
         with pytest.raises(Exception):
             X.ExecutionContext.Load(ctx([bad]))
+
+
+def test_large_context_reads_its_workers_side_by_side_like_in_order():
+    """A saved context of several megabytes is read worker by worker on several
+    threads when it has the shape encoding/json writes; a space after the opening
+    bracket of the workers array sends the same text down the in-order route.
+    Both must give the same context, and every text that does not fit the
+    side-by-side route (separators with white space, a look-alike object nested in
+    an unknown member, a syntax error, a bad ID list) must behave as in order."""
+    X.seed_random(5)
+    ec = X.ExecutionContext.New("http://e:9000", ["test-bucket", "bucket-two"], 100_000, 8, 4096, 16384, startWorkerID=65530)
+    ec.PopulateExisting(seed=9, fraction=0.7, max_write_count=50)
+    text = ec.Marshal()
+    assert len(text) > (8 << 20)
+    in_order = text.replace(b'"workers":[', b'"workers":[ ', 1)
+    a, b = X.ExecutionContext.Load(text), X.ExecutionContext.Load(in_order)
+    assert a.Marshal() == text and b.Marshal() == text
+    assert [w.id for w in a.Workers] == [w.id for w in b.Workers] == [(65530 + i) % 65536 for i in range(8)]
+    assert a.CountExisting() == b.CountExisting() == ec.CountExisting()
+    da, db = a.BuildExistingDescriptors(T0), b.BuildExistingDescriptors(T0)
+    assert da[0].tobytes() == db[0].tobytes() and da[1].tobytes() == db[1].tobytes()
+
+    # separators with white space between the workers
+    spaced = text.replace(b'},{"bucketsWithObject":[', b'} , {"bucketsWithObject":[')
+    assert X.ExecutionContext.Load(spaced).Marshal() == text
+    # an unknown member that holds an object opening like a worker
+    k = text.index(b'"bucketsWithObject":[', len(text) // 2)
+    nested = text[:k] + b'"zz":[{"bucketsWithObject":[]},{"bucketsWithObject":[null]}],' + text[k:]
+    assert X.ExecutionContext.Load(nested).Marshal() == text
+    # a syntax error deep inside: the message (with its offset) is the in-order route's
+    cut = text.index(b'"size":', 2 * len(text) // 3)
+    broken = text[:cut] + b'"size";' + text[cut + 7:]
+    msgs = []
+    for t in (broken, broken.replace(b'"workers":[', b'"workers":[ ', 1)):
+        with pytest.raises(Exception) as ei:
+            X.ExecutionContext.Load(t)
+        msgs.append(str(ei.value))
+    assert f"offset {cut + 6}" in msgs[0] and msgs[1] == msgs[0].replace(f"offset {cut + 6}", f"offset {cut + 7}")
+    # IDs outside the object list in two workers: the first worker's is the one reported
+    tree = json.loads(text)
+    tree["workers"][2]["bucketsWithObject"][1]["objectMeta"]["existingObjectIDs"][5] = 777777
+    tree["workers"][6]["bucketsWithObject"][0]["objectMeta"]["existingObjectIDs"][0] = 888888
+    bad = json.dumps(tree, separators=(",", ":")).encode()
+    for t in (bad, bad.replace(b'"workers":[', b'"workers":[ ', 1)):
+        with pytest.raises(Exception, match="777777"):
+            X.ExecutionContext.Load(t)
+
+
+def test_save_file_equals_marshal_for_a_large_context(tmp_path):
+    X.seed_random(6)
+    ec = X.ExecutionContext.New("e", ["b"], 120_000, 6, 4096, 16384, startWorkerID=1)
+    ec.PopulateExisting(seed=2, fraction=1.0, max_write_count=3)
+    path = str(tmp_path / "ctx.json")
+    ec.SaveContext(path)
+    assert open(path, "rb").read() == ec.Marshal()
+    assert X.ExecutionContext.LoadFile(path).Marshal() == ec.Marshal()
