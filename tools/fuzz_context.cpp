@@ -5,6 +5,11 @@
 //       -o build/fuzz_context && build/fuzz_context 200000
 // Property: LoadSavedContext never crashes or reads out of bounds, and whatever
 // it accepts survives Marshal -> Load -> Marshal unchanged.
+//   build/fuzz_context 300 big
+// mutates a context of several megabytes instead (its workers are then read side
+// by side on several threads) and requires the same verdict and the same context
+// as the in-order route gives for the same text (also worth a run built with
+// -fsanitize=thread instead of address).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +29,52 @@ static uint64_t rnd()
 int main(int argc, char** argv)
 {
     const long iters = argc > 1 ? atol(argv[1]) : 100000;
+    if (argc > 2 && !strcmp(argv[2], "big")) {
+        auto big = oval::runner::NewExecutionContext("http://h:9000", {"bucket-a", "bucket-b"}, 60000, 6, 256, 1024, 3, 0);
+        if (!big.second.nil()) { fprintf(stderr, "%s\n", big.second.msg.c_str()); return 1; }
+        oval::Error pe = oval::runner::PopulateExisting(big.first, 7, 0.6, 50);
+        if (!pe.nil()) { fprintf(stderr, "%s\n", pe.msg.c_str()); return 1; }
+        const std::string seed = oval::runner::MarshalContext(big.first);
+        static const char* bits[] = {"{", "}", "[", "]", ",", ":", "\"", "\\", "null", " ", "{\"bucketsWithObject\":[",
+                                     ",{\"bucketsWithObject\":[]}", "\"zz\":[{\"bucketsWithObject\":[]}],", "\n", "\xFF"};
+        long accepted = 0, rejected = 0;
+        for (long it = 0; it < iters; ++it) {
+            std::string t = seed;
+            const int n_mut = (int)(rnd() % 3);                  // 0: the text as written
+            for (int m = 0; m < n_mut; ++m) {
+                const size_t pos = (size_t)(rnd() % t.size());
+                switch (rnd() % 4) {
+                case 0: t[pos] = (char)(rnd() & 0xFF); break;
+                case 1: t.erase(pos, 1 + (size_t)(rnd() % 8)); break;
+                case 2: t.insert(pos, bits[rnd() % (sizeof bits / sizeof bits[0])]); break;
+                default: {
+                    // at a structural place: just before some worker's opening
+                    const size_t w = t.find("{\"bucketsWithObject\":[", pos);
+                    if (w != std::string::npos) t.insert(w, bits[rnd() % (sizeof bits / sizeof bits[0])]);
+                    break;
+                }
+                }
+            }
+            std::string in_order = t;
+            const size_t wk = in_order.find("\"workers\":[");
+            if (wk != std::string::npos) in_order.insert(wk + 11, " ");
+            auto r1 = oval::runner::LoadSavedContext(t.data(), t.size());
+            auto r2 = oval::runner::LoadSavedContext(in_order.data(), in_order.size());
+            if (r1.second.nil() != r2.second.nil()) {
+                fprintf(stderr, "routes disagree at iteration %ld: side by side '%s', in order '%s'\n", it, r1.second.msg.c_str(),
+                        r2.second.msg.c_str());
+                return 4;
+            }
+            if (!r1.second.nil()) { ++rejected; continue; }
+            ++accepted;
+            if (oval::runner::MarshalContext(r1.first) != oval::runner::MarshalContext(r2.first)) {
+                fprintf(stderr, "routes give different contexts at iteration %ld\n", it);
+                return 5;
+            }
+        }
+        printf("%ld large inputs: %ld accepted by both routes alike, %ld rejected by both\n", iters, accepted, rejected);
+        return 0;
+    }
     auto fresh = oval::runner::NewExecutionContext("http://h:9000/\xC3\xA9<&>", {"bucket-a", "b\"\\\n"}, 12, 3, 256, 1024,
                                                    0xFFFF, 2);
     if (!fresh.second.nil()) { fprintf(stderr, "%s\n", fresh.second.msg.c_str()); return 1; }
