@@ -185,6 +185,18 @@ int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs_host, uint64_t 
  * are derived from the names, whatever the caller's flags say. */
 int oval_layout_reset(oval_ctx* ctx, oval_layout* layout, const oval_obj_desc* descs_host,
                       uint64_t n_obj);
+/* oval_layout_reset for a job whose every batch brings new descriptors (the
+ * worker loop of internal/runner/worker.go:38-121 produces new sizes and write
+ * counts with every PUT): the upload and the index build run on a second stream
+ * of the context, behind the last pass that used THIS layout and nothing else,
+ * so with two layouts taken in turn the tables of batch k+1 travel (64 bytes
+ * per object over PCIe: for 4k-16k objects as long as a pass over the bodies
+ * takes) while the passes of batch k run.  Passes issued afterwards through
+ * this context wait for the tables by themselves.  Passes over the layout
+ * issued through OTHER contexts are the caller's to order against the rebuild.
+ * Otherwise as oval_layout_reset. */
+int oval_layout_reset_ahead(oval_ctx* ctx, oval_layout* layout, const oval_obj_desc* descs_host,
+                            uint64_t n_obj);
 int oval_layout_destroy(oval_ctx* ctx, oval_layout* layout);
 int oval_layout_info(const oval_layout* layout, uint64_t* n_obj, uint64_t* total_units,
                      uint64_t* span_bytes);

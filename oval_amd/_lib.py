@@ -77,6 +77,7 @@ SIGNATURES = {
     "oval_desc_init": (_int, [_vp, _cp, _sz, _cp, _sz, _i64, _i64, _u64, _u64, C.c_uint32, C.c_uint32]),
     "oval_layout_create": (_int, [_vp, _vp, _u64, _pp]),
     "oval_layout_reset": (_int, [_vp, _vp, _vp, _u64]),
+    "oval_layout_reset_ahead": (_int, [_vp, _vp, _vp, _u64]),
     "oval_layout_destroy": (_int, [_vp, _vp]),
     "oval_layout_info": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "oval_layout_launches": (_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -78,6 +78,12 @@ struct oval_layout {
     uint64_t  cap_stage = 0;        // descriptors it holds
     hipStream_t built_on = nullptr; // stream the tables were last built on ...
     hipEvent_t  built_ev = nullptr; // ... and the event that says they are complete
+    // A layout that has been rebuilt ahead of time (oval_layout_reset_ahead) has
+    // every later pass recorded here, so that its next rebuild, on another stream,
+    // waits for the passes that still read its tables and for nothing else.
+    bool        track_use = false;
+    mutable hipEvent_t used_ev = nullptr;
+    mutable bool used = false;      // used_ev has been recorded since the last rebuild
 };
 
 struct oval_timer {
@@ -543,7 +549,10 @@ static int scan_descs(const oval_obj_desc* descs, uint64_t n_obj, uint64_t* tota
     return OVAL_OK;
 }
 
-int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj)
+// `ahead`: the tables go to the device and are built on the context's copy
+// stream, behind the layout's own last pass only, instead of behind everything
+// queued on the context's stream.
+static int layout_rebuild(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj, bool ahead)
 {
     if (!ctx || !l || (!descs && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
     if (l->device != ctx->device) return fail(OVAL_E_INVALID, "layout belongs to device %d, context to %d", l->device, ctx->device);
@@ -561,9 +570,11 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
     l->n_obj = 0; l->n_tiles = 0; l->total_units = 0; l->span_bytes = 0; l->one_level = false; l->no_fill = false;
     const bool grow = n_obj > l->cap_obj || !l->descs_dev || n_tiles > l->cap_tiles || !l->chunk_first_dev ||
                       (one_level && (n_tiles > l->cap_desc_tiles || !l->chunk_desc_dev)) || n_obj > l->cap_stage;
+    hipStream_t const build_stream = ahead ? ctx->copy_stream : ctx->stream;
     if (grow) {
         // a pass that still uses the old tables must finish before they are freed
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (l->built_ev) HIP_TRY(hipEventSynchronize(l->built_ev));
     } else if (l->built_ev) {
         // Same capacity: the new tables are written in stream order behind the
         // passes already issued on this stream, so the device is not waited for;
@@ -593,6 +604,25 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
         HIP_TRY(hipMalloc(&l->chunk_desc_dev, (size_t)cap * oval::kChunksPerTile * sizeof(oval_obj_desc)));
         l->cap_desc_tiles = cap;
     }
+    if (!grow) {
+        // a build still running on another stream writes the same tables
+        if (l->built_ev && l->built_on != build_stream) HIP_TRY(hipStreamWaitEvent(build_stream, l->built_ev, 0));
+        if (ahead) {
+            // the passes that read the old tables were issued on the context's stream
+            if (!l->used_ev) HIP_TRY(hipEventCreateWithFlags(&l->used_ev, hipEventDisableTiming));
+            if (!l->track_use) {
+                // not recorded so far: everything queued on that stream counts as a reader, this once
+                HIP_TRY(hipEventRecord(l->used_ev, ctx->stream));
+                l->used = true;
+            }
+            if (l->used) HIP_TRY(hipStreamWaitEvent(build_stream, l->used_ev, 0));
+        }
+    }
+    if (ahead) {
+        if (!l->used_ev) HIP_TRY(hipEventCreateWithFlags(&l->used_ev, hipEventDisableTiming));
+        l->track_use = true;
+    }
+    l->used = false;
     // The caller's array is not retained and may be pageable: it is copied to a
     // pinned buffer of the layout's here, and goes to the device from there in
     // stream order, so this call does not wait for the device.
@@ -607,13 +637,13 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
         const uint16_t slow_bits = OVAL_DESC_BUCKET_SLOW | OVAL_DESC_KEY_SLOW;
         for (uint64_t i : fix) staged[i].flags = (uint16_t)((staged[i].flags & ~slow_bits) | slow_flags_of(staged[i]));
         HIP_TRY(hipMemcpyAsync(l->descs_dev, l->stage_host, n_obj * sizeof(oval_obj_desc), hipMemcpyHostToDevice,
-                               ctx->stream));
+                               build_stream));
     }
-    HIP_TRY(oval::launch_build_chunk_table(ctx->stream, l->descs_dev, (uint32_t)n_obj, l->chunk_first_dev,
+    HIP_TRY(oval::launch_build_chunk_table(build_stream, l->descs_dev, (uint32_t)n_obj, l->chunk_first_dev,
                                            one_level ? l->chunk_desc_dev : nullptr, n_tiles));
     if (!l->built_ev) HIP_TRY(hipEventCreateWithFlags(&l->built_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(l->built_ev, ctx->stream));
-    l->built_on = ctx->stream;
+    HIP_TRY(hipEventRecord(l->built_ev, build_stream));
+    l->built_on = build_stream;
     l->one_level = one_level;
     l->n_obj = n_obj;
     l->no_fill = no_fill;
@@ -623,10 +653,29 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
     return OVAL_OK;
 }
 
+int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj)
+{
+    return layout_rebuild(ctx, l, descs, n_obj, false);
+}
+
+int oval_layout_reset_ahead(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj)
+{
+    return layout_rebuild(ctx, l, descs, n_obj, true);
+}
+
 // A pass on another stream than the one the tables were built on waits for them.
 static int await_tables(oval_ctx* ctx, const oval_layout* l)
 {
     if (l->built_ev && l->built_on != ctx->stream) HIP_TRY(hipStreamWaitEvent(ctx->stream, l->built_ev, 0));
+    return OVAL_OK;
+}
+
+// After a pass over `l` has been issued on the context's stream.
+static int note_use(oval_ctx* ctx, const oval_layout* l)
+{
+    if (!l->track_use || !l->used_ev) return OVAL_OK;
+    HIP_TRY(hipEventRecord(l->used_ev, ctx->stream));
+    l->used = true;
     return OVAL_OK;
 }
 
@@ -644,6 +693,7 @@ int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj
         if (l->chunk_desc_dev) (void)hipFree(l->chunk_desc_dev);
         if (l->stage_host) (void)hipHostFree(l->stage_host);
         if (l->built_ev) (void)hipEventDestroy(l->built_ev);
+        if (l->used_ev) (void)hipEventDestroy(l->used_ev);
         delete l;
         return rc;
     }
@@ -655,11 +705,13 @@ int oval_layout_destroy(oval_ctx* ctx, oval_layout* l)
 {
     if (!l) return OVAL_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (l->built_ev) (void)hipEventSynchronize(l->built_ev);   // a build on the copy stream still writes the tables
     if (l->descs_dev) (void)hipFree(l->descs_dev);
     if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
     if (l->chunk_desc_dev) (void)hipFree(l->chunk_desc_dev);
     if (l->stage_host) (void)hipHostFree(l->stage_host);
     if (l->built_ev) (void)hipEventDestroy(l->built_ev);
+    if (l->used_ev) (void)hipEventDestroy(l->used_ev);
     delete l;
     return OVAL_OK;
 }
@@ -707,7 +759,7 @@ int oval_fill(oval_ctx* ctx, const oval_layout* l, void* body_dev, uint64_t body
                                   "the reference's Generate fails for it (pattern.go:87-89)");
     if ((rc = await_tables(ctx, l))) return rc;
     HIP_TRY(oval::launch_fill(ctx->stream, cfg_of(ctx), view_of(l), body_dev, 0, tiles_of(l)));
-    return OVAL_OK;
+    return note_use(ctx, l);
 }
 
 int oval_validate(oval_ctx* ctx, const oval_layout* l, const void* body_dev, uint64_t body_bytes,
@@ -723,7 +775,7 @@ int oval_validate(oval_ctx* ctx, const oval_layout* l, const void* body_dev, uin
     HIP_TRY(oval::launch_init_results(ctx->stream, v, results_dev, (unsigned long long*)counters_dev));
     HIP_TRY(oval::launch_validate(ctx->stream, cfg_of(ctx), v, body_dev, 0, tiles_of(l), results_dev,
                                   (unsigned long long*)counters_dev, ctx->tallies_dev));
-    return OVAL_OK;
+    return note_use(ctx, l);
 }
 
 int oval_validate_noalloc(oval_ctx* ctx, const oval_obj_desc* descs_dev, uint64_t n_obj, uint64_t span_bytes,

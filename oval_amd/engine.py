@@ -116,9 +116,13 @@ class Layout:
         check(_lib.lib().oval_layout_launches(self._h, C.byref(f), C.byref(v)))
         return f.value, v.value
 
-    def reset(self, descs: np.ndarray) -> None:
+    def reset(self, descs: np.ndarray, ahead: bool = False) -> None:
+        """New descriptors for this layout; `ahead`: uploaded and indexed on the
+        context's second stream, behind this layout's own last pass only
+        (oval_layout_reset_ahead)."""
         _check_descs(descs)
-        check(_lib.lib().oval_layout_reset(self.ctx.handle, self._h, descs.ctypes.data, len(descs)))
+        fn = _lib.lib().oval_layout_reset_ahead if ahead else _lib.lib().oval_layout_reset
+        check(fn(self.ctx.handle, self._h, descs.ctypes.data, len(descs)))
         self._read_info()
 
     def close(self) -> None:
