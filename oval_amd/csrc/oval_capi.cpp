@@ -945,6 +945,8 @@ int host_layout_for(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, c
 
 }  // namespace
 
+void oval_internal_parallel_for(size_t n, const std::function<void(size_t)>& fn) { TaskPool::get().run(n, fn); }
+
 void oval_internal_parallel_copy(void* dst, const void* src, size_t n)
 {
     std::vector<CopySeg> segs;

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
+
 #include "../../include/oval_hip.h"
 
 int oval_internal_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -20,3 +22,7 @@ int oval_internal_fill_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t 
                             uint64_t body_bytes, hipEvent_t* landed, uint32_t n_landed, bool wait);
 uint32_t oval_internal_host_slices(uint64_t span_bytes);
 uint64_t oval_internal_host_slice_bytes(void);
+
+// fn(0) .. fn(n - 1) on the library's helper threads and the calling thread;
+// returns when all have run.  One such run at a time per process.
+void oval_internal_parallel_for(size_t n, const std::function<void(size_t)>& fn);

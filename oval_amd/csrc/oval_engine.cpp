@@ -331,6 +331,17 @@ Slot* acquire_slot()
     return s;
 }
 
+// A free slot if there is one right now.
+Slot* try_acquire_slot()
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    ensure_inited_locked();
+    if (g.free_slots.empty()) return nullptr;
+    Slot* s = g.free_slots.back();
+    g.free_slots.pop_back();
+    return s;
+}
+
 // Makes `c` the open slot (mu held).  Its first shared use allocates its buffers.
 bool install_open_locked(Slot* c)
 {
@@ -478,51 +489,147 @@ std::string last_error()
     return g.err;
 }
 
+namespace {
+
+// A batch larger than this is cut into sub-batches that travel through several
+// slots at once: while one is on the device the next one's bodies are gathered
+// into pinned memory and the one before is scattered back to the callers'
+// buffers, so the host copies, the PCIe copies and the kernels overlap and the
+// pinned memory a batch needs stays bounded whatever its size.
+constexpr size_t kRunChunkBytes = 16u << 20;   // 4 ... 64 MiB measured alike within noise; below 4 the per-sub-batch calls show
+constexpr size_t kRunChunkJobs = 16384;
+constexpr size_t kRunDepthMax = 6, kRunDepth = 3;
+std::atomic<size_t> g_run_chunk_bytes{kRunChunkBytes}, g_run_depth{kRunDepth};   // set_run_shape(): benchmarks only
+// host copies of a sub-batch are spread over the helper threads from this size on
+constexpr size_t kParallelCopyBytes = 2u << 20;
+
+// fn(first, last) over [0, n) in up to eight ranges of similar byte counts
+template <class Fn>
+void for_job_ranges(Job* const* jobs, size_t n, size_t bytes, const Fn& fn)
+{
+    if (bytes < kParallelCopyBytes || n < 2) {
+        fn((size_t)0, n);
+        return;
+    }
+    const size_t parts = n < 8 ? n : 8;
+    std::vector<size_t> cut(parts + 1, n);
+    cut[0] = 0;
+    size_t acc = 0, k = 1;
+    for (size_t i = 0; i < n && k < parts; ++i) {
+        acc += (size_t)jobs[i]->desc.n_units * kUnit;
+        if (acc * parts >= bytes * k) cut[k++] = i + 1;
+    }
+    oval_internal_parallel_for(parts, [&](size_t p) {
+        if (cut[p] < cut[p + 1]) fn(cut[p], cut[p + 1]);
+    });
+}
+
+struct SubBatch {
+    Slot* s = nullptr;
+    Job* const* jobs = nullptr;
+    size_t n = 0;
+    int rc = OVAL_OK;
+};
+
+// Lays the jobs out in the slot, gathers the bodies to validate and enqueues everything; no wait.
+void sub_start(SubBatch& b)
+{
+    Slot* s = b.s;
+    reset_batch(*s);
+    size_t up = 0, down = 0, nf = 0, nv = 0;
+    for (size_t i = 0; i < b.n; ++i) {
+        const size_t bytes = (size_t)b.jobs[i]->desc.n_units * kUnit;
+        if (b.jobs[i]->is_fill) { down += bytes; nf++; } else { up += bytes; nv++; }
+        if (bytes > s->max_job_bytes) s->max_job_bytes = bytes;
+    }
+    b.rc = ensure_slot(*s, up, down, nf > nv ? nf : nv);
+    if (b.rc) return;
+    for (size_t i = 0; i < b.n; ++i) {
+        Job* j = b.jobs[i];
+        const size_t bytes = (size_t)j->desc.n_units * kUnit;
+        if (j->is_fill) {
+            j->desc.body_offset = s->fill_bytes;
+            s->fdescs[s->n_fill++] = j->desc;
+            s->fill_bytes += bytes;
+        } else {
+            j->desc.body_offset = s->val_bytes;
+            s->vdescs[s->n_val++] = j->desc;
+            s->val_bytes += bytes;
+        }
+    }
+    if (s->n_val)
+        for_job_ranges(b.jobs, b.n, up + down, [&](size_t first, size_t last) {
+            for (size_t i = first; i < last; ++i) {
+                const Job* j = b.jobs[i];
+                if (!j->is_fill) std::memcpy(s->up_host + j->desc.body_offset, j->in, (size_t)j->desc.n_units * kUnit);
+            }
+        });
+    b.rc = submit(*s, false);
+    if (b.rc) (void)oval_ctx_sync(s->ctx);                       // whatever was enqueued before the failure
+}
+
+// Waits for the sub-batch, hands bodies and verdicts to the jobs and gives the slot back.
+void sub_finish(SubBatch& b)
+{
+    Slot* s = b.s;
+    if (!b.rc) b.rc = wait_done(*s, false);
+    if (b.rc) {
+        note_failure(*s);
+        for (size_t i = 0; i < b.n; ++i) { b.jobs[i]->failed = true; b.jobs[i]->err = s->err; }
+    } else {
+        uint32_t vi = 0;
+        for (size_t i = 0; i < b.n; ++i)
+            if (!b.jobs[i]->is_fill) b.jobs[i]->res = s->res_host[vi++];
+        if (s->n_fill)
+            for_job_ranges(b.jobs, b.n, s->fill_bytes + s->val_bytes, [&](size_t first, size_t last) {
+                for (size_t i = first; i < last; ++i) {
+                    Job* j = b.jobs[i];
+                    if (j->is_fill) std::memcpy(j->out, s->down_host + j->desc.body_offset, (size_t)j->desc.n_units * kUnit);
+                }
+            });
+    }
+    release_slot(s);
+    b.s = nullptr;
+}
+
+}  // namespace
+
 void run(Job* const* jobs, size_t n)
 {
     if (n == 0) return;
-    Slot* s = acquire_slot();
-    reset_batch(*s);
-    size_t up = 0, down = 0, nf = 0, nv = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const size_t bytes = (size_t)jobs[i]->desc.n_units * kUnit;
-        if (jobs[i]->is_fill) { down += bytes; nf++; } else { up += bytes; nv++; }
-        if (bytes > s->max_job_bytes) s->max_job_bytes = bytes;
-    }
-    int rc = ensure_slot(*s, up, down, nf > nv ? nf : nv);
-    if (!rc) {
-        for (size_t i = 0; i < n; ++i) {
-            Job* j = jobs[i];
-            const size_t bytes = (size_t)j->desc.n_units * kUnit;
-            if (j->is_fill) {
-                j->desc.body_offset = s->fill_bytes;
-                s->fdescs[s->n_fill++] = j->desc;
-                s->fill_bytes += bytes;
-            } else {
-                j->desc.body_offset = s->val_bytes;
-                s->vdescs[s->n_val++] = j->desc;
-                std::memcpy(s->up_host + s->val_bytes, j->in, bytes);
-                s->val_bytes += bytes;
-            }
+    SubBatch ring[kRunDepthMax];
+    const size_t depth = g_run_depth.load(std::memory_order_relaxed);
+    const size_t chunk_bytes = g_run_chunk_bytes.load(std::memory_order_relaxed);
+    size_t head = 0, live = 0;                                   // ring[head .. head + live) are on the device
+    for (size_t first = 0; first < n;) {
+        // the next sub-batch: jobs [first, last); a job larger than a sub-batch travels alone
+        size_t last = first, bytes = 0;
+        while (last < n && last - first < kRunChunkJobs) {
+            const size_t b = (size_t)jobs[last]->desc.n_units * kUnit;
+            if (last > first && bytes + b > chunk_bytes) break;
+            bytes += b;
+            ++last;
         }
-        rc = submit(*s, false);
-        if (!rc) rc = wait_done(*s, false);
-        else (void)oval_ctx_sync(s->ctx);
-    }
-    if (rc) {
-        note_failure(*s);
-        for (size_t i = 0; i < n; ++i) { jobs[i]->failed = true; jobs[i]->err = s->err; }
-    } else {
-        uint32_t vi = 0;
-        for (size_t i = 0; i < n; ++i) {
-            Job* j = jobs[i];
-            if (j->is_fill)
-                std::memcpy(j->out, s->down_host + j->desc.body_offset, (size_t)j->desc.n_units * kUnit);
-            else
-                j->res = s->res_host[vi++];
+        // A caller never waits for a slot while it holds one (many callers doing so could hold all
+        // of them between them): if none is free it completes its own oldest sub-batch first.
+        Slot* slot = live < depth ? try_acquire_slot() : nullptr;
+        while (!slot && live) {
+            sub_finish(ring[head]);
+            head = (head + 1) % depth;
+            --live;
+            slot = try_acquire_slot();
         }
+        if (!slot) slot = acquire_slot();
+        SubBatch& b = ring[(head + live) % depth];
+        b.s = slot;
+        b.jobs = jobs + first;
+        b.n = last - first;
+        b.rc = OVAL_OK;
+        sub_start(b);
+        ++live;
+        first = last;
     }
-    release_slot(s);
+    for (; live; --live, head = (head + 1) % depth) sub_finish(ring[head]);
 }
 
 void execute(Job& job)
@@ -623,6 +730,12 @@ void set_lanes(int lanes, int blocking)
     std::lock_guard<std::mutex> lk(g.mu);
     if (lanes >= 1) g.n_lanes = lanes > kMaxLanes ? kMaxLanes : lanes;
     if (blocking >= 0) g.blocking = blocking ? 1 : 0;
+}
+
+void set_run_shape(size_t chunk_bytes, int depth)
+{
+    if (chunk_bytes >= (64u << 10)) g_run_chunk_bytes.store(chunk_bytes, std::memory_order_relaxed);
+    if (depth >= 1) g_run_depth.store((size_t)depth > kRunDepthMax ? kRunDepthMax : (size_t)depth, std::memory_order_relaxed);
 }
 
 void set_caller_spin(int ns) { g_spin_ns.store(ns < 0 ? 0 : ns, std::memory_order_relaxed); }

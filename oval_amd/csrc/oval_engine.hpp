@@ -43,6 +43,9 @@ void set_lanes(int lanes, int blocking);
 // Shape of the tree through which the callers of a finished batch wake each other: the lane wakes
 // `roots` callers, each caller wakes `fanout` more (defaults 1 and 4; values < 1 keep the setting).
 void set_wake_tree(int fanout, int roots);
+// How run() cuts a large batch: sub-batches of at most `chunk_bytes` (0 keeps the setting), `depth`
+// of them in flight (1..6, 0 keeps it).  Defaults 16 MiB and 3.  For benchmarks.
+void set_run_shape(size_t chunk_bytes, int depth);
 // A caller polls its wake word this long before it sleeps on it (default 0: sleep at once).
 void set_caller_spin(int ns);
 void stats(uint64_t* batches, uint64_t* jobs);

@@ -17,6 +17,7 @@
 
 #include "../../include/oval_hip.h"
 #include "../../include/oval_pattern.h"
+#include "oval_capi_internal.h"
 #include "oval_engine.hpp"
 #include "oval_gostr.h"
 #include "oval_trimspace.h"
@@ -240,6 +241,8 @@ void SetMicroBatching(bool enable, int windowMicros, size_t maxBytes)
 
 void SetBatchLanes(int lanes, int blockingSync) { engine::set_lanes(lanes, blockingSync); }
 
+void SetBatchShape(size_t chunkBytes, int depth) { engine::set_run_shape(chunkBytes, depth); }
+
 void SetWakeTuning(int fanout, int roots, int spinNanos)
 {
     engine::set_wake_tree(fanout, roots);
@@ -368,16 +371,33 @@ std::pair<std::vector<uint8_t>, Error> Generate(int64_t dataSize, int64_t worker
     return {std::move(data), err};
 }
 
+// fn(first, last) over the items of a batch form; a large batch's items are
+// prepared (names padded, descriptors built) and judged on several host threads.
+template <class Fn>
+static void for_item_ranges(size_t n, const Fn& fn)
+{
+    constexpr size_t kPerRange = 2048;
+    if (n < 2 * kPerRange) {
+        fn((size_t)0, n);
+        return;
+    }
+    const size_t parts = (n + kPerRange - 1) / kPerRange;
+    oval_internal_parallel_for(parts, [&](size_t p) { fn(p * kPerRange, (p + 1) * kPerRange < n ? (p + 1) * kPerRange : n); });
+}
+
 std::vector<Error> GenerateBatch(const std::vector<GenerateItem>& items)
 {
     std::vector<Error> errs(items.size());
     std::vector<Job> jobs(items.size());
     std::vector<Job*> run;
-    for (size_t i = 0; i < items.size(); ++i) {
-        const GenerateItem& it = items[i];
-        errs[i] = prepare_generate(it.dataSize, it.workerID, it.bucketName, it.obj, it.out, jobs[i]);
+    for_item_ranges(items.size(), [&](size_t first, size_t last) {
+        for (size_t i = first; i < last; ++i) {
+            const GenerateItem& it = items[i];
+            errs[i] = prepare_generate(it.dataSize, it.workerID, it.bucketName, it.obj, it.out, jobs[i]);
+        }
+    });
+    for (size_t i = 0; i < items.size(); ++i)
         if (errs[i].nil() && jobs[i].desc.n_units > 0) run.push_back(&jobs[i]);
-    }
     if (!run.empty()) {
         engine::run(run.data(), run.size());
         for (Job* j : run)
@@ -763,15 +783,20 @@ std::vector<Error> ValidBatch(const std::vector<ValidItem>& items)
     std::vector<Job> jobs(items.size());
     std::vector<ValidState> sts(items.size());
     std::vector<Job*> run;
-    for (size_t i = 0; i < items.size(); ++i) {
-        const ValidItem& it = items[i];
-        errs[i] = prepare_valid(it.workerID, it.expectedBucketName, it.obj, it.body, it.bodyLen, sts[i], jobs[i]);
-        if (errs[i].nil() && sts[i].has_job) run.push_back(&jobs[i]);
-    }
-    if (!run.empty()) engine::run(run.data(), run.size());
+    for_item_ranges(items.size(), [&](size_t first, size_t last) {
+        for (size_t i = first; i < last; ++i) {
+            const ValidItem& it = items[i];
+            errs[i] = prepare_valid(it.workerID, it.expectedBucketName, it.obj, it.body, it.bodyLen, sts[i], jobs[i]);
+        }
+    });
     for (size_t i = 0; i < items.size(); ++i)
-        if (errs[i].nil())
-            errs[i] = finish_valid(items[i].workerID, items[i].obj, items[i].body, sts[i], jobs[i]);
+        if (errs[i].nil() && sts[i].has_job) run.push_back(&jobs[i]);
+    if (!run.empty()) engine::run(run.data(), run.size());
+    for_item_ranges(items.size(), [&](size_t first, size_t last) {
+        for (size_t i = first; i < last; ++i)
+            if (errs[i].nil())
+                errs[i] = finish_valid(items[i].workerID, items[i].obj, items[i].body, sts[i], jobs[i]);
+    });
     return errs;
 }
 

@@ -179,6 +179,10 @@ void SetBatchLanes(int lanes, int blockingSync);
 // more; defaults 1 and 4) and how long a caller polls before it sleeps (default 0).  Values < 0 keep
 // the setting.  For benchmarks.
 void SetWakeTuning(int fanout, int roots, int spinNanos);
+// How GenerateBatch / ValidBatch cut a large batch into sub-batches that travel through the device one
+// behind the other: at most `chunkBytes` each (0 keeps the setting; default 16 MiB), `depth` in flight
+// (0 keeps it; default 3).  For benchmarks.
+void SetBatchShape(size_t chunkBytes, int depth);
 // Time the lane threads spent per phase since the last reset, summed over
 // lanes: [0] ns waiting for callers still copying their bodies in, [1] ns
 // enqueueing the batch, [2] ns waiting for the device, [3] ns publishing and
