@@ -111,6 +111,23 @@ def test_decide_size_mean_matches_survey(oracle):
     assert 9300 < mean < 9700
 
 
+def test_decide_size_against_an_independent_log2(oracle):
+    """The reference holds no vector for the value DecideSize returns for a given
+    sample (parity unpinned: math.Log2 is restated from the Go standard library's
+    portable implementation, as it rounds on amd64 where Go does not fuse
+    multiply-adds).  What can be checked without Go: the restated logarithm agrees
+    with an independent one (numpy's) so closely that over 150,000 samples and a
+    range of 4 million sizes not one truncated product differs — a wrong
+    coefficient or a dropped term of relative size 1e-11 would already show."""
+    rng = np.random.default_rng(12)
+    ys = rng.random(150_000)
+    lo, hi = 256, 1 << 30
+    n = (hi - lo) // 256 + 1
+    want = lo + 256 * np.floor(np.float64(n) * -np.log2(1.0 - 0.5 * ys)).astype(np.int64)
+    got = np.array([oracle.decide_size(lo, hi, float(y)) for y in ys], dtype=np.int64)
+    assert int((got != want).sum()) == 0
+
+
 def test_key_format(oracle):                                  # object.go:48-50, README.md:71-74
     assert oracle.generate_key(0) == "ov0000000000"
     assert oracle.generate_key((2 << 24) + 0xE2) == "ov00020000e2"
