@@ -180,6 +180,17 @@ def test_hex_dump_layout(oracle):
     assert len(part) == 61 + 10 + 2
 
 
+def test_hex_dump_matches_the_go_documentation_example(oracle):
+    """encoding/hex's own documented example (ExampleDump in the Go standard
+    library's package documentation; not a file of the reference): 42 bytes, so the
+    third line is a partial one.  The only published vector for the partial-line
+    layout that the short-read message of Valid (pattern.go:126) prints."""
+    want = ("00000000  47 6f 20 69 73 20 61 6e  20 6f 70 65 6e 20 73 6f  |Go is an open so|\n"
+            "00000010  75 72 63 65 20 70 72 6f  67 72 61 6d 6d 69 6e 67  |urce programming|\n"
+            "00000020  20 6c 61 6e 67 75 61 67  65 2e                    | language.|\n")
+    assert oracle.hex_dump(b"Go is an open source programming language.") == want
+
+
 def test_dump_annotations(oracle):
     assert oracle.dump("") == ""
     text = oracle.hex_dump(bytes(256))
