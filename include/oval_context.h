@@ -109,6 +109,17 @@ int oval_execctx_build_descs(const oval_execctx* ec, uint64_t unix_micro, size_t
                              uint64_t cap, uint64_t* n_out, uint64_t* body_bytes_out,
                              char* err, size_t err_cap);
 
+/* The same objects as 12-byte records plus one segment per worker and bucket that
+ * has any, for oval_layout_reset_compact (the descriptors are then written on
+ * the device).  *n_segs_out / *n_obj_out / *body_bytes_out are always set;
+ * segs_out and recs_out are written when both are given and large enough.
+ * Fails when an object's key does not follow from its ID (a hand-edited saved
+ * context): such a context needs oval_execctx_build_descs. */
+int oval_execctx_build_compact(const oval_execctx* ec, uint64_t unix_micro, size_t worker_begin,
+                               size_t worker_end, oval_obj_segment* segs_out, uint64_t seg_cap,
+                               oval_obj_rec* recs_out, uint64_t rec_cap, uint64_t* n_segs_out,
+                               uint64_t* n_obj_out, uint64_t* body_bytes_out, char* err, size_t err_cap);
+
 #ifdef __cplusplus
 }
 #endif

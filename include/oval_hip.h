@@ -197,6 +197,53 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* layout, const oval_obj_desc* d
  * Otherwise as oval_layout_reset. */
 int oval_layout_reset_ahead(oval_ctx* ctx, oval_layout* layout, const oval_obj_desc* descs_host,
                             uint64_t n_obj);
+/* ---- layouts from compact records ---------------------------------------
+ * What the reference keeps per object is a key that follows from the object ID
+ * (object.go:48-50: "ov" + 10 hex digits), a size and a write count
+ * (object.go:21-25); bucket, worker ID and key range belong to the worker
+ * (runner.go:117-125).  A batch whose bodies lie back to back can therefore be
+ * described by 12 bytes per object plus one segment per run of objects that
+ * share the rest, and the 64-byte descriptors are written on the device: a fifth
+ * of the bytes over PCIe and no table to build, check and stage on the host.
+ * Record i belongs to the segment with first_obj <= i < first_obj + n_obj; the
+ * segments cover records 0 .. n_obj-1 in order.  Object i starts where object
+ * i-1 ends (object 0 at offset 0) and is described from its unit 0. */
+typedef struct oval_obj_rec {
+    uint32_t obj_id;       /* key = "ov" + %010x of (segment.key_id_base + obj_id)        */
+    uint32_t write_count;  /* uint32(obj.WriteCount), pattern.go:101                     */
+    uint32_t n_units;      /* obj.Size / 256                                             */
+} oval_obj_rec;            /* 12 bytes */
+
+typedef struct oval_obj_segment {
+    uint8_t  bucket[16];   /* space padded, as oval_obj_desc.bucket                      */
+    uint64_t key_id_base;  /* (runnerID << 32) + (worker index << 24), runner.go:119-124 */
+    uint64_t unix_micro;
+    uint32_t worker_id;
+    uint32_t first_obj;    /* index of the segment's first record                        */
+    uint32_t n_obj;
+    uint8_t  bucket_len;
+    uint8_t  reserved;
+    uint16_t flags;        /* OVAL_DESC_* bits that hold for every object of the segment */
+} oval_obj_segment;        /* 48 bytes */
+
+/* Formats the bucket like oval_desc_init and derives the flags (a bucket with
+ * white space at an edge, a worker ID outside uint32, a bucket whose rune count
+ * differs from its byte count). */
+int oval_segment_init(oval_obj_segment* seg, const char* bucket, size_t bucket_len, int64_t worker_id,
+                      uint64_t unix_micro, uint64_t key_id_base, uint32_t first_obj, uint32_t n_obj);
+/* oval_layout_reset from records and segments in host memory (copied before the
+ * call returns); with OVAL_RESET_AHEAD in `flags` as oval_layout_reset_ahead
+ * orders it.  OVAL_E_LAYOUT if the segments do not cover the records in
+ * order, if a key would need more than 10 hex digits, or if the bodies exceed
+ * the 1 TiB batch limit. */
+#define OVAL_RESET_AHEAD 0x1u
+int oval_layout_reset_compact(oval_ctx* ctx, oval_layout* layout, const oval_obj_segment* segs_host,
+                              uint64_t n_segs, const oval_obj_rec* recs_host, uint64_t n_obj, uint32_t flags);
+/* Copies descriptors [first, first + n) of a layout's device table back to the
+ * host and waits (tests and debugging: the table of a compact layout exists
+ * only on the device). */
+int oval_layout_read_descs(oval_ctx* ctx, const oval_layout* layout, uint64_t first, uint64_t n,
+                           oval_obj_desc* out_host);
 int oval_layout_destroy(oval_ctx* ctx, oval_layout* layout);
 int oval_layout_info(const oval_layout* layout, uint64_t* n_obj, uint64_t* total_units,
                      uint64_t* span_bytes);

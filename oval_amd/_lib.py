@@ -46,7 +46,23 @@ RESULT_DTYPE = np.dtype(
         ("strict_first_bad_unit", "<u4"),
     ]
 )
+# struct oval_obj_rec (12 bytes) and struct oval_obj_segment (48 bytes): a batch in compact form
+REC_DTYPE = np.dtype([("obj_id", "<u4"), ("write_count", "<u4"), ("n_units", "<u4")])
+SEGMENT_DTYPE = np.dtype(
+    [
+        ("bucket", "u1", (16,)),
+        ("key_id_base", "<u8"),
+        ("unix_micro", "<u8"),
+        ("worker_id", "<u4"),
+        ("first_obj", "<u4"),
+        ("n_obj", "<u4"),
+        ("bucket_len", "u1"),
+        ("reserved", "u1"),
+        ("flags", "<u2"),
+    ]
+)
 assert DESC_DTYPE.itemsize == 64 and RESULT_DTYPE.itemsize == 16
+assert REC_DTYPE.itemsize == 12 and SEGMENT_DTYPE.itemsize == 48
 
 
 class OvalError(RuntimeError):
@@ -78,6 +94,9 @@ SIGNATURES = {
     "oval_layout_create": (_int, [_vp, _vp, _u64, _pp]),
     "oval_layout_reset": (_int, [_vp, _vp, _vp, _u64]),
     "oval_layout_reset_ahead": (_int, [_vp, _vp, _vp, _u64]),
+    "oval_layout_reset_compact": (_int, [_vp, _vp, _vp, _u64, _vp, _u64, C.c_uint32]),
+    "oval_layout_read_descs": (_int, [_vp, _vp, _u64, _u64, _vp]),
+    "oval_segment_init": (_int, [_vp, _cp, _sz, _i64, _u64, _u64, C.c_uint32, C.c_uint32]),
     "oval_layout_destroy": (_int, [_vp, _vp]),
     "oval_layout_info": (_int, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     "oval_layout_launches": (_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -161,6 +180,8 @@ SIGNATURES = {
     "oval_execctx_populate": (_int, [_vp, _u64, C.c_double, _i64, _cp, _sz]),
     "oval_execctx_build_descs": (_int, [_vp, _u64, _sz, _sz, _vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64),
                                         _cp, _sz]),
+    "oval_execctx_build_compact": (_int, [_vp, _u64, _sz, _sz, _vp, _u64, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64),
+                                          C.POINTER(_u64), _cp, _sz]),
 }
 
 

@@ -341,3 +341,49 @@ class DeviceCorruption:
             body[self.offs] = self.vals
         if self.flip_idx.numel():
             body[self.flip_idx] = body[self.flip_idx] ^ self.flip_mask
+
+
+def compact_from_descs(descs: np.ndarray):
+    """(segs, recs) for oval_layout_reset_compact from a descriptor table whose
+    bodies lie back to back from offset 0, whose objects start at unit 0 and whose
+    keys have the reference's form "ov" + 10 hex digits (object.go:48-50).  A new
+    segment starts wherever bucket, worker ID, time or the key's upper 16 bits
+    (process and worker index, runner.go:119-124) change."""
+    from ._lib import REC_DTYPE, SEGMENT_DTYPE
+
+    n = len(descs)
+    recs = np.zeros(n, dtype=REC_DTYPE)
+    if n == 0:
+        return np.zeros(0, dtype=SEGMENT_DTYPE), recs
+    units = descs["n_units"].astype(np.uint64)
+    starts = np.concatenate([[0], np.cumsum(units)[:-1]]).astype(np.uint64) * np.uint64(UNIT)
+    if (descs["body_offset"] != starts).any() or descs["first_unit"].any() or (descs["key_len"] != 12).any():
+        raise ValueError("the compact form describes whole objects laid out back to back")
+    k = descs["key"]
+    if (k[:, 0] != ord("o")).any() or (k[:, 1] != ord("v")).any():
+        raise ValueError("keys must be \"ov\" + 10 hex digits")
+    digits = k[:, 2:].astype(np.int64)
+    vals = np.where(digits >= ord("a"), digits - ord("a") + 10, digits - ord("0"))
+    if ((vals < 0) | (vals > 15)).any() or ((digits > ord("9")) & (digits < ord("a"))).any():
+        raise ValueError("keys must be \"ov\" + 10 lower-case hex digits")
+    ids = np.zeros(n, dtype=np.uint64)
+    for c in range(10):
+        ids = (ids << np.uint64(4)) | vals[:, c].astype(np.uint64)
+    base = ids & ~np.uint64(0xFFFFFF)
+    recs["obj_id"] = (ids - base).astype(np.uint32)
+    recs["write_count"] = descs["write_count"]
+    recs["n_units"] = descs["n_units"]
+    same = ((base[1:] == base[:-1]) & (descs["worker_id"][1:] == descs["worker_id"][:-1]) &
+            (descs["unix_micro"][1:] == descs["unix_micro"][:-1]) & (descs["flags"][1:] == descs["flags"][:-1]) &
+            (descs["bucket_len"][1:] == descs["bucket_len"][:-1]) & (descs["bucket"][1:] == descs["bucket"][:-1]).all(axis=1))
+    first = np.concatenate([[0], np.flatnonzero(~same) + 1])
+    segs = np.zeros(len(first), dtype=SEGMENT_DTYPE)
+    segs["bucket"] = descs["bucket"][first]
+    segs["bucket_len"] = descs["bucket_len"][first]
+    segs["flags"] = descs["flags"][first]
+    segs["worker_id"] = descs["worker_id"][first]
+    segs["unix_micro"] = descs["unix_micro"][first]
+    segs["key_id_base"] = base[first]
+    segs["first_obj"] = first
+    segs["n_obj"] = np.diff(np.concatenate([first, [n]]))
+    return segs, recs

@@ -274,3 +274,23 @@ class ExecutionContext:
                                               refs.ctypes.data, n.value, C.byref(n), C.byref(nbytes), err,
                                               _ERR_CAP), err)
         return descs, refs, nbytes.value
+
+    def BuildExistingCompact(self, unix_micro: int, worker_begin: int = 0, worker_end: int = None):
+        """(segs, recs, body_bytes): the same objects, in the same order, as 12-byte
+        records plus one segment per worker and bucket, for Layout.reset_compact."""
+        from ._lib import REC_DTYPE, SEGMENT_DTYPE
+
+        L = _lib.lib()
+        if worker_end is None:
+            worker_end = len(self.Workers)
+        ns, n, nbytes = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        err = C.create_string_buffer(_ERR_CAP)
+        _raise(L.oval_execctx_build_compact(self._h, unix_micro, worker_begin, worker_end, None, 0, None, 0,
+                                            C.byref(ns), C.byref(n), C.byref(nbytes), err, _ERR_CAP), err)
+        segs = np.zeros(ns.value, dtype=SEGMENT_DTYPE)
+        recs = np.zeros(n.value, dtype=REC_DTYPE)
+        if n.value:
+            _raise(L.oval_execctx_build_compact(self._h, unix_micro, worker_begin, worker_end, segs.ctypes.data,
+                                                len(segs), recs.ctypes.data, len(recs), C.byref(ns), C.byref(n),
+                                                C.byref(nbytes), err, _ERR_CAP), err)
+        return segs, recs, nbytes.value

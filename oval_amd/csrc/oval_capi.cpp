@@ -74,8 +74,10 @@ struct oval_layout {
     uint64_t  cap_obj = 0;       // descriptors the device table can hold
     uint32_t  cap_tiles = 0;    // tiles the chunk table has room for (kChunksPerTile entries each)
     uint32_t  cap_desc_tiles = 0;   // likewise for chunk_desc_dev
-    void*     stage_host = nullptr; // pinned copy of the caller's descriptors on their way to the device
-    uint64_t  cap_stage = 0;        // descriptors it holds
+    void*     stage_host = nullptr; // pinned copy of the caller's descriptors (or records) on their way to the device
+    uint64_t  cap_stage_bytes = 0;
+    void*     compact_dev = nullptr; // records, segments and block sums of a layout built from compact records
+    uint64_t  cap_compact_bytes = 0;
     hipStream_t built_on = nullptr; // stream the tables were last built on ...
     hipEvent_t  built_ev = nullptr; // ... and the event that says they are complete
     // A layout that has been rebuilt ahead of time (oval_layout_reset_ahead) has
@@ -549,28 +551,37 @@ static int scan_descs(const oval_obj_desc* descs, uint64_t n_obj, uint64_t* tota
     return OVAL_OK;
 }
 
-// `ahead`: the tables go to the device and are built on the context's copy
-// stream, behind the layout's own last pass only, instead of behind everything
-// queued on the context's stream.
-static int layout_rebuild(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj, bool ahead)
-{
-    if (!ctx || !l || (!descs && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
-    if (l->device != ctx->device) return fail(OVAL_E_INVALID, "layout belongs to device %d, context to %d", l->device, ctx->device);
-    uint64_t total_units = 0, span_bytes = 0;
+// What a rebuild of a layout is to hold, known before anything touches the device.
+struct LayoutShape {
+    uint64_t n_obj = 0, total_units = 0, span_bytes = 0;
+    uint64_t stage_bytes = 0;     // pinned staging the upload needs
+    uint64_t compact_bytes = 0;   // device memory for records, segments and block sums (compact form only)
     bool no_fill = false;
-    std::vector<uint64_t> fix;
-    int rc = scan_descs(descs, n_obj, &total_units, &span_bytes, &no_fill, &fix);
-    if (rc) return rc;
-    const uint64_t span_units = span_bytes / OVAL_UNIT_SIZE;
-    const uint32_t n_tiles = (uint32_t)((span_units + oval::kUnitsPerTile - 1) / oval::kUnitsPerTile);
-    const bool one_level = n_obj != 0 && span_bytes / n_obj < (256ull << 10);
+    uint32_t n_tiles = 0;
+    bool one_level = false;
+};
+
+// First half of a rebuild: capacity (grow-only) and ordering against whatever
+// still reads or writes the old tables.  `ahead`: the tables go to the device
+// and are built on the context's copy stream, behind the layout's own last pass
+// only, instead of behind everything queued on the context's stream.
+static int layout_prepare(oval_ctx* ctx, oval_layout* l, LayoutShape& sh, bool ahead, hipStream_t* build_stream_out)
+{
+    const uint64_t span_units = sh.span_bytes / OVAL_UNIT_SIZE;
+    sh.n_tiles = (uint32_t)((span_units + oval::kUnitsPerTile - 1) / oval::kUnitsPerTile);
+    sh.one_level = sh.n_obj != 0 && sh.span_bytes / sh.n_obj < (256ull << 10);
+    const uint64_t n_obj = sh.n_obj;
+    const uint32_t n_tiles = sh.n_tiles;
+    const bool one_level = sh.one_level;
     HIP_TRY(hipSetDevice(ctx->device));
     // Until every table is in place the layout describes nothing, so that a
     // failure below cannot leave counts that point into freed or missing tables.
     l->n_obj = 0; l->n_tiles = 0; l->total_units = 0; l->span_bytes = 0; l->one_level = false; l->no_fill = false;
     const bool grow = n_obj > l->cap_obj || !l->descs_dev || n_tiles > l->cap_tiles || !l->chunk_first_dev ||
-                      (one_level && (n_tiles > l->cap_desc_tiles || !l->chunk_desc_dev)) || n_obj > l->cap_stage;
+                      (one_level && (n_tiles > l->cap_desc_tiles || !l->chunk_desc_dev)) ||
+                      sh.stage_bytes > l->cap_stage_bytes || sh.compact_bytes > l->cap_compact_bytes;
     hipStream_t const build_stream = ahead ? ctx->copy_stream : ctx->stream;
+    *build_stream_out = build_stream;
     if (grow) {
         // a pass that still uses the old tables must finish before they are freed
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -604,6 +615,16 @@ static int layout_rebuild(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* de
         HIP_TRY(hipMalloc(&l->chunk_desc_dev, (size_t)cap * oval::kChunksPerTile * sizeof(oval_obj_desc)));
         l->cap_desc_tiles = cap;
     }
+    if (sh.stage_bytes > l->cap_stage_bytes) {
+        if (l->stage_host) { (void)hipHostFree(l->stage_host); l->stage_host = nullptr; l->cap_stage_bytes = 0; }
+        HIP_TRY(hipHostMalloc(&l->stage_host, sh.stage_bytes, hipHostMallocDefault));
+        l->cap_stage_bytes = sh.stage_bytes;
+    }
+    if (sh.compact_bytes > l->cap_compact_bytes) {
+        if (l->compact_dev) { (void)hipFree(l->compact_dev); l->compact_dev = nullptr; l->cap_compact_bytes = 0; }
+        HIP_TRY(hipMalloc(&l->compact_dev, sh.compact_bytes));
+        l->cap_compact_bytes = sh.compact_bytes;
+    }
     if (!grow) {
         // a build still running on another stream writes the same tables
         if (l->built_ev && l->built_on != build_stream) HIP_TRY(hipStreamWaitEvent(build_stream, l->built_ev, 0));
@@ -623,15 +644,43 @@ static int layout_rebuild(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* de
         l->track_use = true;
     }
     l->used = false;
+    return OVAL_OK;
+}
+
+// Second half: the chunk index over the descriptor table now on its way on
+// `build_stream`, the event that says the tables are complete, and the counts.
+static int layout_finish(oval_layout* l, const LayoutShape& sh, hipStream_t build_stream)
+{
+    HIP_TRY(oval::launch_build_chunk_table(build_stream, l->descs_dev, (uint32_t)sh.n_obj, l->chunk_first_dev,
+                                           sh.one_level ? l->chunk_desc_dev : nullptr, sh.n_tiles));
+    if (!l->built_ev) HIP_TRY(hipEventCreateWithFlags(&l->built_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(l->built_ev, build_stream));
+    l->built_on = build_stream;
+    l->one_level = sh.one_level;
+    l->n_obj = sh.n_obj;
+    l->no_fill = sh.no_fill;
+    l->total_units = sh.total_units;
+    l->span_bytes = sh.span_bytes;
+    l->n_tiles = sh.n_tiles;
+    return OVAL_OK;
+}
+
+static int layout_rebuild(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj, bool ahead)
+{
+    if (!ctx || !l || (!descs && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
+    if (l->device != ctx->device) return fail(OVAL_E_INVALID, "layout belongs to device %d, context to %d", l->device, ctx->device);
+    LayoutShape sh;
+    std::vector<uint64_t> fix;
+    int rc = scan_descs(descs, n_obj, &sh.total_units, &sh.span_bytes, &sh.no_fill, &fix);
+    if (rc) return rc;
+    sh.n_obj = n_obj;
+    sh.stage_bytes = n_obj * sizeof(oval_obj_desc);
+    hipStream_t build_stream = nullptr;
+    if ((rc = layout_prepare(ctx, l, sh, ahead, &build_stream))) return rc;
     // The caller's array is not retained and may be pageable: it is copied to a
     // pinned buffer of the layout's here, and goes to the device from there in
     // stream order, so this call does not wait for the device.
     if (n_obj) {
-        if (n_obj > l->cap_stage) {
-            if (l->stage_host) { (void)hipHostFree(l->stage_host); l->stage_host = nullptr; l->cap_stage = 0; }
-            HIP_TRY(hipHostMalloc(&l->stage_host, n_obj * sizeof(oval_obj_desc), hipHostMallocDefault));
-            l->cap_stage = n_obj;
-        }
         oval_internal_parallel_copy(l->stage_host, descs, n_obj * sizeof(oval_obj_desc));
         oval_obj_desc* staged = static_cast<oval_obj_desc*>(l->stage_host);
         const uint16_t slow_bits = OVAL_DESC_BUCKET_SLOW | OVAL_DESC_KEY_SLOW;
@@ -639,18 +688,7 @@ static int layout_rebuild(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* de
         HIP_TRY(hipMemcpyAsync(l->descs_dev, l->stage_host, n_obj * sizeof(oval_obj_desc), hipMemcpyHostToDevice,
                                build_stream));
     }
-    HIP_TRY(oval::launch_build_chunk_table(build_stream, l->descs_dev, (uint32_t)n_obj, l->chunk_first_dev,
-                                           one_level ? l->chunk_desc_dev : nullptr, n_tiles));
-    if (!l->built_ev) HIP_TRY(hipEventCreateWithFlags(&l->built_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(l->built_ev, build_stream));
-    l->built_on = build_stream;
-    l->one_level = one_level;
-    l->n_obj = n_obj;
-    l->no_fill = no_fill;
-    l->total_units = total_units;
-    l->span_bytes = span_bytes;
-    l->n_tiles = n_tiles;
-    return OVAL_OK;
+    return layout_finish(l, sh, build_stream);
 }
 
 int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj)
@@ -661,6 +699,112 @@ int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs,
 int oval_layout_reset_ahead(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj)
 {
     return layout_rebuild(ctx, l, descs, n_obj, true);
+}
+
+static_assert(sizeof(oval_obj_rec) == 12, "record must be 12 bytes");
+static_assert(sizeof(oval_obj_segment) == 48 && offsetof(oval_obj_segment, key_id_base) == 16 &&
+              offsetof(oval_obj_segment, worker_id) == 32 && offsetof(oval_obj_segment, flags) == 46, "segment layout");
+
+int oval_segment_init(oval_obj_segment* seg, const char* bucket, size_t bucket_len, int64_t worker_id,
+                      uint64_t unix_micro, uint64_t key_id_base, uint32_t first_obj, uint32_t n_obj)
+{
+    if (!seg) return fail(OVAL_E_INVALID, "NULL argument");
+    // the same formatting and flags as a descriptor's, taken from one built for a key of the reference's shape
+    oval_obj_desc d;
+    int rc = oval_desc_init(&d, bucket, bucket_len, "ov0000000000", 12, 0, worker_id, unix_micro, 0, 0, 0);
+    if (rc) return rc;
+    std::memset(seg, 0, sizeof *seg);
+    std::memcpy(seg->bucket, d.bucket, sizeof seg->bucket);
+    seg->key_id_base = key_id_base;
+    seg->unix_micro = unix_micro;
+    seg->worker_id = d.worker_id;
+    seg->first_obj = first_obj;
+    seg->n_obj = n_obj;
+    seg->bucket_len = d.bucket_len;
+    seg->flags = d.flags;
+    return OVAL_OK;
+}
+
+int oval_layout_reset_compact(oval_ctx* ctx, oval_layout* l, const oval_obj_segment* segs, uint64_t n_segs,
+                              const oval_obj_rec* recs, uint64_t n_obj, uint32_t flags)
+{
+    if (!ctx || !l || (!recs && n_obj) || (!segs && n_segs)) return fail(OVAL_E_INVALID, "NULL argument");
+    if (flags & ~OVAL_RESET_AHEAD) return fail(OVAL_E_INVALID, "unknown flags 0x%x", flags);
+    if (l->device != ctx->device) return fail(OVAL_E_INVALID, "layout belongs to device %d, context to %d", l->device, ctx->device);
+    if (n_obj >= 0xFFFFFFF0ull) return fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
+    if (n_segs > n_obj) return fail(OVAL_E_LAYOUT, "%llu segments for %llu objects: a segment holds at least one",
+                                    (unsigned long long)n_segs, (unsigned long long)n_obj);
+    LayoutShape sh;
+    sh.n_obj = n_obj;
+    // the segments cover the records in order; per segment the units and the highest object ID
+    uint64_t next = 0;
+    for (uint64_t k = 0; k < n_segs; ++k) {
+        if (segs[k].first_obj != next || segs[k].n_obj == 0)
+            return fail(OVAL_E_LAYOUT, "segment %llu starts at record %u with %u objects; record %llu is the next uncovered one",
+                        (unsigned long long)k, segs[k].first_obj, segs[k].n_obj, (unsigned long long)next);
+        if (segs[k].bucket_len > OVAL_MAX_BUCKET_LEN)
+            return fail(OVAL_E_LAYOUT, "segment %llu: bucket length %u exceeds 16", (unsigned long long)k, segs[k].bucket_len);
+        next += segs[k].n_obj;
+        sh.no_fill |= (segs[k].flags & OVAL_DESC_NO_FILL) != 0;
+    }
+    if (next != n_obj)
+        return fail(OVAL_E_LAYOUT, "the segments cover %llu records, the table holds %llu", (unsigned long long)next,
+                    (unsigned long long)n_obj);
+    std::vector<uint64_t> seg_units(n_segs, 0);
+    std::vector<uint32_t> seg_max_id(n_segs, 0);
+    TaskPool::get().run(n_segs, [&](size_t k) {
+        uint64_t units = 0;
+        uint32_t max_id = 0;
+        const oval_obj_rec* r = recs + segs[k].first_obj;
+        for (uint32_t i = 0; i < segs[k].n_obj; ++i) {
+            units += r[i].n_units;
+            if (r[i].obj_id > max_id) max_id = r[i].obj_id;
+        }
+        seg_units[k] = units;
+        seg_max_id[k] = max_id;
+    });
+    for (uint64_t k = 0; k < n_segs; ++k) {
+        if (segs[k].key_id_base + seg_max_id[k] >= (1ull << 40) || segs[k].key_id_base >= (1ull << 40))
+            return fail(OVAL_E_LAYOUT, "segment %llu: object ID %llu needs more than 10 hex digits, the key would exceed 12 bytes",
+                        (unsigned long long)k, (unsigned long long)(segs[k].key_id_base + seg_max_id[k]));
+        sh.total_units += seg_units[k];
+    }
+    if (sh.total_units >= 0xFFFFFF00ull)
+        return fail(OVAL_E_LAYOUT, "batch spans %llu bytes; the limit is just under 1 TiB",
+                    (unsigned long long)(sh.total_units * OVAL_UNIT_SIZE));
+    sh.span_bytes = sh.total_units * OVAL_UNIT_SIZE;
+    // staging and device scratch: records | segments (16-byte aligned) | block sums
+    const uint64_t recs_bytes = (n_obj * sizeof(oval_obj_rec) + 15) & ~15ull;
+    const uint64_t segs_bytes = n_segs * sizeof(oval_obj_segment);
+    const uint64_t sums_bytes = (uint64_t)oval::compact_blocks((uint32_t)n_obj) * 8;
+    sh.stage_bytes = recs_bytes + segs_bytes;
+    sh.compact_bytes = recs_bytes + segs_bytes + sums_bytes;
+    hipStream_t build_stream = nullptr;
+    int rc = layout_prepare(ctx, l, sh, (flags & OVAL_RESET_AHEAD) != 0, &build_stream);
+    if (rc) return rc;
+    if (n_obj) {
+        char* stage = static_cast<char*>(l->stage_host);
+        oval_internal_parallel_copy(stage, recs, n_obj * sizeof(oval_obj_rec));
+        std::memcpy(stage + recs_bytes, segs, segs_bytes);
+        char* dev = static_cast<char*>(l->compact_dev);
+        HIP_TRY(hipMemcpyAsync(dev, stage, recs_bytes + segs_bytes, hipMemcpyHostToDevice, build_stream));
+        HIP_TRY(oval::launch_expand_descs(build_stream, dev, (uint32_t)n_obj, dev + recs_bytes, (uint32_t)n_segs,
+                                          reinterpret_cast<unsigned long long*>(dev + recs_bytes + segs_bytes), l->descs_dev));
+    }
+    return layout_finish(l, sh, build_stream);
+}
+
+int oval_layout_read_descs(oval_ctx* ctx, const oval_layout* l, uint64_t first, uint64_t n, oval_obj_desc* out_host)
+{
+    if (!ctx || !l || (!out_host && n)) return fail(OVAL_E_INVALID, "NULL argument");
+    if (first > l->n_obj || n > l->n_obj - first)
+        return fail(OVAL_E_RANGE, "descriptors [%llu, %llu) of a table of %llu", (unsigned long long)first,
+                    (unsigned long long)(first + n), (unsigned long long)l->n_obj);
+    if (n == 0) return OVAL_OK;
+    if (l->built_ev) HIP_TRY(hipEventSynchronize(l->built_ev));
+    HIP_TRY(hipMemcpy(out_host, static_cast<const oval_obj_desc*>(l->descs_dev) + first, n * sizeof(oval_obj_desc),
+                      hipMemcpyDeviceToHost));
+    return OVAL_OK;
 }
 
 // A pass on another stream than the one the tables were built on waits for them.
@@ -692,6 +836,7 @@ int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj
         if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
         if (l->chunk_desc_dev) (void)hipFree(l->chunk_desc_dev);
         if (l->stage_host) (void)hipHostFree(l->stage_host);
+        if (l->compact_dev) (void)hipFree(l->compact_dev);
         if (l->built_ev) (void)hipEventDestroy(l->built_ev);
         if (l->used_ev) (void)hipEventDestroy(l->used_ev);
         delete l;
@@ -710,6 +855,7 @@ int oval_layout_destroy(oval_ctx* ctx, oval_layout* l)
     if (l->chunk_first_dev) (void)hipFree(l->chunk_first_dev);
     if (l->chunk_desc_dev) (void)hipFree(l->chunk_desc_dev);
     if (l->stage_host) (void)hipHostFree(l->stage_host);
+    if (l->compact_dev) (void)hipFree(l->compact_dev);
     if (l->built_ev) (void)hipEventDestroy(l->built_ev);
     if (l->used_ev) (void)hipEventDestroy(l->used_ev);
     delete l;

@@ -1063,6 +1063,81 @@ Error BuildExistingDescriptorsInto(const ExecutionContext& ec, uint64_t unixMicr
     return Error::Nil();
 }
 
+Error BuildExistingCompactInto(const ExecutionContext& ec, uint64_t unixMicro, size_t workerBegin, size_t workerEnd,
+                               oval_obj_segment* segs, size_t segCap, oval_obj_rec* recs, size_t recCap,
+                               size_t* nSegsOut, size_t* nObjOut, uint64_t* bodyBytesOut)
+{
+    if (workerEnd > ec.Workers.size()) workerEnd = ec.Workers.size();
+    std::vector<Segment> parts;
+    size_t n = 0;
+    for (size_t w = workerBegin; w < workerEnd; ++w)
+        for (size_t b = 0; b < ec.Workers[w].BucketsWithObject.size(); ++b) {
+            const size_t have = ec.Workers[w].BucketsWithObject[b].ObjectMeta.ExistingObjectIDs.size();
+            if (have == 0) continue;                             // a segment holds at least one object
+            Segment s;
+            s.worker = (uint32_t)w;
+            s.bucket = (uint32_t)b;
+            s.first = n;
+            n += have;
+            parts.push_back(std::move(s));
+        }
+    if (n >= 0xFFFFFFF0ull) return Error::New("too many existing objects for one batch");
+    if (nSegsOut) *nSegsOut = parts.size();
+    if (nObjOut) *nObjOut = n;
+    const bool write = recs && segs && recCap >= n && segCap >= parts.size();
+    for_each_segment(parts, n, [&](Segment& s) {
+        const Worker& wk = ec.Workers[s.worker];
+        const BucketWithObject& bo = wk.BucketsWithObject[s.bucket];
+        const object::ObjectMeta& om = bo.ObjectMeta;
+        if (om.KeyIDOffset < 0) { s.err = Error::New("negative keyIDOffset"); return; }
+        uint64_t units = 0;
+        size_t i = s.first;
+        char key[24];
+        for (int64_t objID : om.ExistingObjectIDs) {
+            if (objID < 0 || (uint64_t)objID >= om.ObjectList.size() || objID > (int64_t)UINT32_MAX) {
+                s.err = Error::New("existingObjectIDs holds " + std::to_string(objID) + ", outside the object list");
+                return;
+            }
+            const object::Object& obj = om.ObjectList[(size_t)objID];
+            if (obj.Size < 0) { s.err = Error::New("object " + obj.Key + " has a negative size"); return; }
+            const uint64_t u = (uint64_t)obj.Size / (uint64_t)pattern::dataUnitSize;
+            if (u > UINT32_MAX) { s.err = Error::New("object " + obj.Key + " is too large"); return; }
+            if (!write) { units += u; continue; }                // sizes only: the keys are judged when the table is written
+            // the key the device will write: "ov" + %010x (object.go:48-50)
+            const uint64_t id = (uint64_t)om.KeyIDOffset + (uint64_t)objID;
+            static const char hexd[] = "0123456789abcdef";
+            key[0] = 'o'; key[1] = 'v';
+            for (int d = 0; d < 10; ++d) key[2 + d] = hexd[(id >> (4 * (9 - d))) & 15u];
+            if (id >> 40 || obj.Key.size() != 12 || std::memcmp(obj.Key.data(), key, 12) != 0) {
+                s.err = Error::New("object " + obj.Key + " does not carry the key of ID " + std::to_string(id) +
+                                   ": the compact form cannot describe it");
+                return;
+            }
+            recs[i] = oval_obj_rec{(uint32_t)objID, (uint32_t)obj.WriteCount, (uint32_t)u};
+            units += u;
+            ++i;
+        }
+        s.units = units;
+    });
+    uint64_t off = 0;
+    for (size_t k = 0; k < parts.size(); ++k) {
+        Segment& s = parts[k];
+        if (!s.err.nil()) return s.err;                          // the first in table order
+        off += s.units * (uint64_t)pattern::dataUnitSize;
+        if (!write) continue;
+        const Worker& wk = ec.Workers[s.worker];
+        const BucketWithObject& bo = wk.BucketsWithObject[s.bucket];
+        // Valid and Generate cut the bucket name to 16 bytes (pattern.go:74-76,119-121)
+        const std::string bucket = bo.BucketName.substr(0, object::MaxBucketNameLength);
+        const int rc = oval_segment_init(&segs[k], bucket.data(), bucket.size(), wk.id, unixMicro,
+                                         (uint64_t)bo.ObjectMeta.KeyIDOffset, (uint32_t)s.first,
+                                         (uint32_t)bo.ObjectMeta.ExistingObjectIDs.size());
+        if (rc != OVAL_OK) return Error::New("bucket " + bo.BucketName + ": " + oval_last_error());
+    }
+    if (bodyBytesOut) *bodyBytesOut = off;
+    return Error::Nil();
+}
+
 std::pair<DescriptorTable, Error> BuildExistingDescriptors(const ExecutionContext& ec, uint64_t unixMicro,
                                                            size_t workerBegin, size_t workerEnd)
 {
@@ -1330,6 +1405,24 @@ int oval_execctx_build_descs(const oval_execctx* ec, uint64_t unix_micro, size_t
         (size_t)cap, &n, &bytes);
     if (!e.nil()) return put_err(e, err, err_cap);
     if (n_out) *n_out = n;
+    if (body_bytes_out) *body_bytes_out = bytes;
+    return put_err(oval::Error::Nil(), err, err_cap);
+}
+
+int oval_execctx_build_compact(const oval_execctx* ec, uint64_t unix_micro, size_t worker_begin, size_t worker_end,
+                               oval_obj_segment* segs_out, uint64_t seg_cap, oval_obj_rec* recs_out, uint64_t rec_cap,
+                               uint64_t* n_segs_out, uint64_t* n_obj_out, uint64_t* body_bytes_out, char* err,
+                               size_t err_cap)
+{
+    if (!ec) return OVAL_E_INVALID;
+    size_t n_segs = 0, n_obj = 0;
+    uint64_t bytes = 0;
+    const oval::Error e = oval::runner::BuildExistingCompactInto(ec->ec, unix_micro, worker_begin, worker_end, segs_out,
+                                                                 (size_t)seg_cap, recs_out, (size_t)rec_cap, &n_segs,
+                                                                 &n_obj, &bytes);
+    if (!e.nil()) return put_err(e, err, err_cap);
+    if (n_segs_out) *n_segs_out = n_segs;
+    if (n_obj_out) *n_obj_out = n_obj;
     if (body_bytes_out) *body_bytes_out = bytes;
     return put_err(oval::Error::Nil(), err, err_cap);
 }

@@ -118,6 +118,14 @@ std::pair<DescriptorTable, Error> BuildExistingDescriptors(const ExecutionContex
 // both NULL only *nOut and *bodyBytesOut are computed: how large a table the caller has to provide.
 Error BuildExistingDescriptorsInto(const ExecutionContext& ec, uint64_t unixMicro, size_t workerBegin, size_t workerEnd,
                                    oval_obj_desc* descs, ObjectRef* refs, size_t cap, size_t* nOut, uint64_t* bodyBytesOut);
+// The same objects in compact form (12-byte records plus one segment per worker
+// and bucket that has any: oval_layout_reset_compact turns them into descriptors
+// on the device).  Fails if an object's key is not generateKey(KeyIDOffset + its
+// index), which a hand-edited saved context can hold: such a context needs the
+// descriptor form.  With recs and segs NULL only the counts are computed.
+Error BuildExistingCompactInto(const ExecutionContext& ec, uint64_t unixMicro, size_t workerBegin, size_t workerEnd,
+                               oval_obj_segment* segs, size_t segCap, oval_obj_rec* recs, size_t recCap,
+                               size_t* nSegsOut, size_t* nObjOut, uint64_t* bodyBytesOut);
 uint64_t CountExisting(const ExecutionContext& ec);
 
 // Puts a context into the state a run leaves behind, without running one: every

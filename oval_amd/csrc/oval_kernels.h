@@ -46,6 +46,13 @@ struct LaunchCfg {
 
 hipError_t launch_build_chunk_table(hipStream_t s, const void* descs, uint32_t n_obj,
                                     uint32_t* chunk_first, void* chunk_desc, uint32_t n_tiles);
+// The descriptor table written on the device from oval_obj_rec[n_obj] and
+// oval_obj_segment[n_segs] (both in device memory; the segments cover the
+// records in order): bodies back to back from offset 0.  `block_units_dev` is
+// scratch of compact_blocks(n_obj) u64.
+uint32_t compact_blocks(uint32_t n_obj);
+hipError_t launch_expand_descs(hipStream_t s, const void* recs_dev, uint32_t n_obj, const void* segs_dev, uint32_t n_segs,
+                               unsigned long long* block_units_dev, void* descs_dev);
 // Tiles one fill launch covers when `range` tiles are to be filled: bounded by
 // the HIP grid limit and by the lookup-table bytes a launch may depend on, and
 // chosen so that the launches of the range are of equal size.

@@ -83,6 +83,131 @@ __global__ __launch_bounds__(256) void build_chunk_table_kernel(const u32x4* __r
 }
 
 // ---------------------------------------------------------------------------
+// Descriptor table built on the device from compact records (12 bytes per
+// object: object ID, write count, units) and a short segment table (one entry
+// per run of objects that share bucket, worker ID, time and key range): what
+// the reference keeps per object is just that (internal/object/object.go:21-25),
+// the key follows from the ID (object.go:48-50: "ov" + 10 hex digits) and
+// bodies lie back to back, so the 64-byte descriptors need not cross PCIe.
+// Three launches: units per block of 1024 objects; the running sum over the
+// blocks (one workgroup); then every block scans its own objects and writes
+// their descriptors.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRecsPerBlock = 1024;                      // 256 threads x 4 records
+
+struct RecTriple { uint32_t obj_id, write_count, n_units; };
+
+__device__ __forceinline__ uint32_t block_sum_u32(uint32_t v, uint32_t* lds)
+{
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    const uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[wv] = v;
+    __syncthreads();
+    const uint32_t total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(256) void rec_block_units_kernel(const RecTriple* __restrict__ recs, uint32_t n_obj,
+                                                              unsigned long long* __restrict__ block_units)
+{
+    __shared__ uint32_t lds[4];
+    const uint32_t base = blockIdx.x * kRecsPerBlock + threadIdx.x * 4u;
+    unsigned long long mine = 0;
+    for (uint32_t k = 0; k < 4u; ++k)
+        if (base + k < n_obj) mine += recs[base + k].n_units;
+    // a block's units fit 42 bits; summed in two 32-bit halves
+    const uint32_t lo = block_sum_u32((uint32_t)(mine & 0xFFFFFu), lds);              // 20 bits x 256 threads
+    const uint32_t hi = block_sum_u32((uint32_t)(mine >> 20), lds);
+    if (threadIdx.x == 0) block_units[blockIdx.x] = ((unsigned long long)hi << 20) + lo;
+}
+
+// block_units[b] := units in blocks 0 .. b-1 (in place), one workgroup
+__global__ __launch_bounds__(1024) void scan_block_units_kernel(unsigned long long* __restrict__ block_units, uint32_t n_blocks)
+{
+    __shared__ unsigned long long part[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < n_blocks ? block_units[i] : 0ull;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 1024u; d <<= 1) {                // inclusive scan in shared memory
+            const unsigned long long add = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const unsigned long long c = carry;
+        if (i < n_blocks) block_units[i] = c + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023u) carry = c + part[1023];
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ uint32_t hex_pair(uint32_t byte)      // two lower-case hex digits, high digit in the low byte
+{
+    const uint32_t h = byte >> 4, l = byte & 15u;
+    return (h + (h < 10u ? 48u : 87u)) | ((l + (l < 10u ? 48u : 87u)) << 8);
+}
+
+__global__ __launch_bounds__(256) void expand_descs_kernel(const RecTriple* __restrict__ recs, uint32_t n_obj,
+                                                           const oval_obj_segment* __restrict__ segs, uint32_t n_segs,
+                                                           const unsigned long long* __restrict__ block_base,
+                                                           u32x4* __restrict__ descs)
+{
+    __shared__ unsigned long long wave_units[4];
+    const uint32_t base = blockIdx.x * kRecsPerBlock + threadIdx.x * 4u;
+    RecTriple r[4];
+    unsigned long long mine = 0;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        r[k] = base + k < n_obj ? recs[base + k] : RecTriple{0u, 0u, 0u};
+        mine += r[k].n_units;
+    }
+    // exclusive scan of `mine` over the workgroup: within the wavefront by shuffles, across the four through LDS
+    unsigned long long incl = mine;
+    const int lane = threadIdx.x & 63;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    const uint32_t wv = threadIdx.x >> 6;
+    if (lane == 63) wave_units[wv] = incl;
+    __syncthreads();
+    unsigned long long start = block_base[blockIdx.x] + incl - mine;
+    for (uint32_t w = 0; w < wv; ++w) start += wave_units[w];
+    if (base >= n_obj) return;
+    // the segment of this thread's first object; its others walk on from there
+    uint32_t lo = 0, hi = n_segs - 1u;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if (segs[mid].first_obj <= base) lo = mid; else hi = mid - 1u;
+    }
+    uint32_t sg = lo;
+    for (uint32_t k = 0; k < 4u && base + k < n_obj; ++k) {
+        const uint32_t i = base + k;
+        while (sg + 1u < n_segs && segs[sg + 1u].first_obj <= i) ++sg;
+        const oval_obj_segment& s = segs[sg];
+        const u32x4* sb = reinterpret_cast<const u32x4*>(s.bucket);
+        const unsigned long long id = s.key_id_base + r[k].obj_id;      // below 2^40 (checked on the host)
+        // "ov" + 10 hex digits, most significant first (object.go:48-50)
+        const uint32_t k0 = 0x766Fu | (hex_pair((uint32_t)(id >> 32) & 0xFFu) << 16);
+        const uint32_t k1 = hex_pair((uint32_t)(id >> 24) & 0xFFu) | (hex_pair((uint32_t)(id >> 16) & 0xFFu) << 16);
+        const uint32_t k2 = hex_pair((uint32_t)(id >> 8) & 0xFFu) | (hex_pair((uint32_t)id & 0xFFu) << 16);
+        const unsigned long long off = start * OVAL_UNIT_SIZE;
+        descs[4u * i] = sb[0];
+        descs[4u * i + 1u] = (u32x4){k0, k1, k2, r[k].write_count};
+        descs[4u * i + 2u] = (u32x4){0u, s.worker_id, (uint32_t)s.unix_micro, (uint32_t)(s.unix_micro >> 32)};
+        descs[4u * i + 3u] = (u32x4){(uint32_t)off, (uint32_t)(off >> 32), r[k].n_units,
+                                     (uint32_t)s.bucket_len | (12u << 8) | ((uint32_t)s.flags << 16)};
+        start += r[k].n_units;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Reads the part of the chunk table, of the per-chunk descriptor copies (if
 // the layout has them) and of the descriptor table that the chunks
 // [chunk_begin, chunk_end) refer to, so that it sits in the memory-side cache
@@ -658,6 +783,21 @@ hipError_t launch_build_chunk_table(hipStream_t s, const void* descs, uint32_t n
     const uint32_t blocks = (n_chunks + 255u) / 256u;
     build_chunk_table_kernel<<<blocks, 256, 0, s>>>(static_cast<const u32x4*>(descs), n_obj, chunk_first,
                                                     static_cast<u32x4*>(chunk_desc), n_chunks);
+    return hipGetLastError();
+}
+
+uint32_t compact_blocks(uint32_t n_obj) { return (n_obj + kRecsPerBlock - 1u) / kRecsPerBlock; }
+
+hipError_t launch_expand_descs(hipStream_t s, const void* recs_dev, uint32_t n_obj, const void* segs_dev, uint32_t n_segs,
+                               unsigned long long* block_units_dev, void* descs_dev)
+{
+    if (n_obj == 0 || n_segs == 0) return hipSuccess;
+    const uint32_t n_blocks = compact_blocks(n_obj);
+    const RecTriple* recs = static_cast<const RecTriple*>(recs_dev);
+    rec_block_units_kernel<<<n_blocks, 256, 0, s>>>(recs, n_obj, block_units_dev);
+    scan_block_units_kernel<<<1, 1024, 0, s>>>(block_units_dev, n_blocks);
+    expand_descs_kernel<<<n_blocks, 256, 0, s>>>(recs, n_obj, static_cast<const oval_obj_segment*>(segs_dev), n_segs,
+                                                 block_units_dev, static_cast<u32x4*>(descs_dev));
     return hipGetLastError();
 }
 

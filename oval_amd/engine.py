@@ -125,6 +125,25 @@ class Layout:
         check(fn(self.ctx.handle, self._h, descs.ctypes.data, len(descs)))
         self._read_info()
 
+    def reset_compact(self, segs: np.ndarray, recs: np.ndarray, ahead: bool = False) -> None:
+        """New contents from 12-byte records and a segment table
+        (oval_layout_reset_compact): the descriptors are written on the device;
+        `ahead` as in reset()."""
+        if segs.dtype != _lib.SEGMENT_DTYPE or recs.dtype != _lib.REC_DTYPE:
+            raise TypeError("segs / recs must have SEGMENT_DTYPE / REC_DTYPE")
+        if not (segs.flags["C_CONTIGUOUS"] and recs.flags["C_CONTIGUOUS"]):
+            raise ValueError("segs / recs must be contiguous")
+        check(_lib.lib().oval_layout_reset_compact(self.ctx.handle, self._h, segs.ctypes.data, len(segs),
+                                                   recs.ctypes.data, len(recs), 1 if ahead else 0))
+        self._read_info()
+
+    def read_descs(self, first: int = 0, n: int | None = None) -> np.ndarray:
+        """Descriptors [first, first + n) of the device table, copied back (waits)."""
+        n = self.n_obj - first if n is None else n
+        out = np.zeros(n, dtype=_lib.DESC_DTYPE)
+        check(_lib.lib().oval_layout_read_descs(self.ctx.handle, self._h, first, n, out.ctypes.data))
+        return out
+
     def close(self) -> None:
         if self._h:
             _lib.lib().oval_layout_destroy(self.ctx.handle, self._h)

@@ -417,3 +417,67 @@ def test_save_file_equals_marshal_for_a_large_context(tmp_path):
     ec.SaveContext(path)
     assert open(path, "rb").read() == ec.Marshal()
     assert X.ExecutionContext.LoadFile(path).Marshal() == ec.Marshal()
+
+
+def _expand_compact(segs, recs):
+    """Descriptors from compact records, the way the device writes them."""
+    from oval_amd._lib import DESC_DTYPE
+
+    d = np.zeros(len(recs), dtype=DESC_DTYPE)
+    units = recs["n_units"].astype(np.uint64)
+    d["body_offset"] = (np.concatenate([[0], np.cumsum(units)[:-1]]) * np.uint64(256)).astype(np.uint64) if len(recs) else 0
+    d["n_units"] = recs["n_units"]
+    d["write_count"] = recs["write_count"]
+    d["key_len"] = 12
+    for s in segs:
+        a, b = int(s["first_obj"]), int(s["first_obj"]) + int(s["n_obj"])
+        d["bucket"][a:b] = s["bucket"]
+        d["bucket_len"][a:b] = s["bucket_len"]
+        d["flags"][a:b] = s["flags"]
+        d["worker_id"][a:b] = s["worker_id"]
+        d["unix_micro"][a:b] = s["unix_micro"]
+        ids = recs["obj_id"][a:b].astype(np.uint64) + np.uint64(s["key_id_base"])
+        keys = np.array([list(b"ov%010x" % int(i)) for i in ids], dtype=np.uint8).reshape(-1, 12)
+        d["key"][a:b] = keys
+    return d
+
+
+def test_compact_table_describes_the_same_objects_as_the_descriptor_table():
+    X.seed_random(8)
+    ec = X.ExecutionContext.New("e", ["test-bucket", "a-bucket-name-of-20"], 3000, 5, 256, 8192, startWorkerID=65534, runnerID=3)
+    ec.PopulateExisting(seed=4, fraction=0.6, max_write_count=40)
+    # one worker's second bucket holds nothing: no segment for it
+    om = ec.Workers[2].BucketsWithObject[1].ObjectMeta
+    while om.PopExistingRandomObject() is not None:
+        pass
+    descs, refs, nbytes = ec.BuildExistingDescriptors(T0)
+    segs, recs, nbytes2 = ec.BuildExistingCompact(T0)
+    assert len(segs) == 9 and len(recs) == len(descs) and nbytes2 == nbytes
+    assert _expand_compact(segs, recs).tobytes() == descs.tobytes()
+    assert (recs["obj_id"] == refs["obj_id"]).all()
+    # a rank's share
+    d2, _, nb2 = ec.BuildExistingDescriptors(T0, 1, 3)
+    s2, r2, nb3 = ec.BuildExistingCompact(T0, 1, 3)
+    assert nb2 == nb3 and _expand_compact(s2, r2).tobytes() == d2.tobytes() and int(s2["first_obj"][0]) == 0
+    # a key that does not follow from its ID cannot be described in 12 bytes
+    tree = json.loads(ec.Marshal())
+    tree["workers"][1]["bucketsWithObject"][0]["objectMeta"]["objectList"][
+        tree["workers"][1]["bucketsWithObject"][0]["objectMeta"]["existingObjectIDs"][0]]["key"] = "renamed-key"
+    odd = X.ExecutionContext.Load(json.dumps(tree))
+    odd.BuildExistingDescriptors(T0)
+    with pytest.raises(Exception, match="renamed-key"):
+        odd.BuildExistingCompact(T0)
+
+
+def test_compact_form_of_a_synthetic_batch_expands_to_its_descriptors():
+    from oval_amd.batch import WorkerSpace, compact_from_descs, synthetic_batch
+
+    space = WorkerSpace(num_obj=6000, num_worker=12, runner_id=2, start_worker_id=0xFFFA)
+    descs = synthetic_batch(space, range(3, 9), "test-bucket", 256, 16384, seed=4, unix_micro=T0)
+    segs, recs = compact_from_descs(descs)
+    assert len(segs) == 6 and int(segs["n_obj"].sum()) == len(descs) == 3000
+    assert _expand_compact(segs, recs).tobytes() == descs.tobytes()
+    gapped = descs.copy()
+    gapped["body_offset"][5:] += 256
+    with pytest.raises(ValueError):
+        compact_from_descs(gapped)

@@ -139,3 +139,124 @@ def test_worker_loop_then_blackout_revalidation_in_one_batch(oracle):
             assert str(e.value) == oracle.valid(wid, bucket, obj.Key, obj.Size, obj.WriteCount, data)[2]
     finally:
         ctx.close()
+
+
+def _segment(bucket, worker_id, key_id_base, first, n, unix_micro=T0):
+    import ctypes as C
+
+    from oval_amd import _lib
+
+    s = np.zeros(1, dtype=_lib.SEGMENT_DTYPE)
+    b = bucket.encode()
+    _lib.check(_lib.lib().oval_segment_init(s.ctypes.data, b, len(b), worker_id, unix_micro, key_id_base, first, n))
+    return s
+
+
+def test_descriptors_written_on_the_device_equal_the_host_table(oracle):
+    """oval_layout_reset_compact: 12-byte records + segments -> descriptors on the
+    device.  The table read back must equal oval_desc_init's byte for byte, and
+    fill / validate over it must give the oracle's bytes and verdicts.  Shapes:
+    a context's own compact form; 1.3 M tiny objects (the running sum crosses
+    more than 1024 blocks of 1024); segment seams inside one thread's four
+    records; zero-unit objects; a bucket that can never validate, a worker ID
+    outside uint32, IDs at the top of the 40-bit key range."""
+    import torch
+
+    from oval_amd import _lib, context as X, engine
+    from oval_amd.batch import build_descs, make_keys
+
+    ctx = engine.Context.on_torch_stream(0)
+    try:
+        layout = engine.Layout(ctx, build_descs("b", ["k"], [1], 1, T0, [256]))
+        # (1) a populated context, both forms
+        X.seed_random(3)
+        ec = X.ExecutionContext.New("e", ["test-bucket", "bucket-two"], 40_000, 7, 256, 16384, startWorkerID=0xFFF0, runnerID=0xAB)
+        ec.PopulateExisting(seed=5, fraction=0.8, max_write_count=100)
+        descs, _, nbytes = ec.BuildExistingDescriptors(T0)
+        segs, recs, nbytes2 = ec.BuildExistingCompact(T0)
+        layout.reset_compact(segs, recs)
+        assert (layout.n_obj, layout.span_bytes) == (len(descs), nbytes) and nbytes2 == nbytes
+        assert layout.read_descs().tobytes() == descs.tobytes()
+        body = torch.full((nbytes,), 0xEE, dtype=torch.uint8, device="cuda:0")
+        layout.fill(body)
+        ctx.sync()
+        exp = np.full(nbytes, 0xEE, dtype=np.uint8)
+        oracle.fill_batch(descs.view(oracle.DESC_DTYPE), exp)
+        host = body.cpu().numpy()
+        assert np.array_equal(host, exp)
+        host[int(descs["body_offset"][1234]) + 3 * 256 + 29] ^= 2
+        host[int(descs["body_offset"][len(descs) - 1]) + 20] ^= 1
+        body.copy_(torch.from_numpy(host))
+        res, cnt = layout.validate(body)
+        ctx.sync()
+        got = engine.results_to_numpy(res, len(descs))
+        want, wcnt = oracle.validate_batch(descs.view(oracle.DESC_DTYPE), host)
+        for f in want.dtype.names:
+            assert np.array_equal(got[f], want[f]), f
+        assert np.array_equal(cnt.cpu().numpy().astype(np.uint64), wcnt)
+
+        # (2) hand-made shapes against oval_desc_init through build_descs
+        rng = np.random.default_rng(9)
+        shapes = [
+            [("test-bucket", 7, 0, 1_300_000)],                                          # > 1024 blocks
+            [("b", 1, 5 << 24, 1), ("b", 2, 6 << 24, 2), ("c", 3, 7 << 24, 1), ("d", 4, 8 << 24, 1021), ("e", 5, 0, 3)],
+            [(" edge", 9, 1 << 32, 700), ("sixteen-chars-ok!", -5, (0xFF << 32) + (0xFF << 24), 2000)],
+        ]
+        for shape in shapes:
+            seg_list, rec_list, want_descs, first = [], [], [], 0
+            for bucket, wid, base, n in shape:
+                ids = rng.permutation(min(n * 2, 1 << 24))[:n].astype(np.uint32)
+                if base == (0xFF << 32) + (0xFF << 24):
+                    ids[0] = (1 << 24) - 1                                               # the largest key: ovffffffffff
+                units = rng.integers(0, 3 if n > 100_000 else 40, size=n).astype(np.uint32)
+                wcs = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+                seg_list.append(_segment(bucket, wid, base, first, n))
+                r = np.zeros(n, dtype=_lib.REC_DTYPE)
+                r["obj_id"], r["write_count"], r["n_units"] = ids, wcs, units
+                rec_list.append(r)
+                keys = make_keys(ids.astype(np.uint64) + np.uint64(base))
+                assert bytes(keys[0]) == b"ov%010x" % (base + int(ids[0]))
+                want_descs.append((bucket, keys, wcs, wid, units))
+                first += n
+            segs, recs = np.concatenate(seg_list), np.concatenate(rec_list)
+            layout.reset_compact(segs, recs)
+            got = layout.read_descs()
+            at, off = 0, 0
+            for bucket, keys, wcs, wid, units in want_descs:
+                d = build_descs(bucket, keys, wcs.astype(np.int64), wid, T0, units.astype(np.int64) * 256)
+                d["body_offset"] += np.uint64(off)
+                if wid < 0:
+                    d["flags"] |= _lib.DESC_WORKER_OOR
+                assert got[at:at + len(d)].tobytes() == d.tobytes(), (bucket, at)
+                at += len(d)
+                off += int(units.astype(np.int64).sum()) * 256
+            assert layout.span_bytes == off and layout.n_obj == at
+            if off <= (2 << 30):
+                body = torch.full((max(off, 256),), 0xEE, dtype=torch.uint8, device="cuda:0")
+                layout.fill(body)
+                res, cnt = layout.validate(body)
+                ctx.sync()
+                exp = np.full(max(off, 256), 0xEE, dtype=np.uint8)
+                oracle.fill_batch(got.view(oracle.DESC_DTYPE), exp)
+                host = body.cpu().numpy()
+                assert np.array_equal(host, exp)
+                want, wcnt = oracle.validate_batch(got.view(oracle.DESC_DTYPE), host)
+                r = engine.results_to_numpy(res, len(got))
+                for f in want.dtype.names:
+                    assert np.array_equal(r[f], want[f]), f
+                assert np.array_equal(cnt.cpu().numpy().astype(np.uint64), wcnt)
+
+        # (3) what the call refuses
+        one = np.zeros(4, dtype=_lib.REC_DTYPE)
+        with pytest.raises(_lib.OvalError, match="next uncovered"):
+            layout.reset_compact(np.concatenate([_segment("b", 1, 0, 0, 2), _segment("b", 1, 0, 3, 1)]), one)
+        with pytest.raises(_lib.OvalError, match="cover 3 records"):
+            layout.reset_compact(_segment("b", 1, 0, 0, 3), one)
+        big = one.copy(); big["obj_id"][2] = 5
+        with pytest.raises(_lib.OvalError, match="10 hex digits"):
+            layout.reset_compact(_segment("b", 1, (1 << 40) - 4, 0, 4), big)
+        layout.reset_compact(np.zeros(0, dtype=_lib.SEGMENT_DTYPE), np.zeros(0, dtype=_lib.REC_DTYPE))
+        assert layout.n_obj == 0
+        layout.close()
+    finally:
+        ctx.close()

@@ -51,6 +51,15 @@ def main():
     torch.cuda.set_stream(stream)
     ctx = engine.Context(0, stream.cuda_stream)
     layout = timed("layout (upload descriptors, chunk table)", lambda: (engine.Layout(ctx, descs), ctx.sync())[0])
+    # the same table from 12-byte records, its descriptors written on the device
+    segs, recs, nbytes_c = timed("compact table (12-byte records + segments)", lambda: ec2.BuildExistingCompact(T0))
+    assert nbytes_c == nbytes and len(recs) == len(descs)
+    layout_c = engine.Layout(ctx, descs[:1])
+    timed("layout from the compact table, first time", lambda: (layout_c.reset_compact(segs, recs), ctx.sync()))
+    timed("layout from the compact table, again", lambda: (layout_c.reset_compact(segs, recs), ctx.sync()))
+    timed("layout from descriptors, again", lambda: (layout.reset(descs), ctx.sync()))
+    assert layout_c.read_descs(len(descs) - 1000, 1000).tobytes() == descs[-1000:].tobytes()
+    layout = layout_c
     body = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
     results = torch.empty((len(descs), 4), dtype=torch.int32, device="cuda:0")
     counters = torch.zeros(engine.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")

@@ -51,13 +51,20 @@ def main():
     print(f"  oval_layout_reset, new table each time: call returns after {1e3 * np.median(call):.2f} ms, tables on the "
           f"device after {1e3 * np.median(done):.2f} ms")
 
-    def run(n_layouts, ahead=False):
+    from oval_amd.batch import compact_from_descs
+    compact = [compact_from_descs(b) for b in batches]
+    print(f"  compact form: {compact[0][1].nbytes / 1e6:.0f} MB of records + {len(compact[0][0])} segments")
+
+    def run(n_layouts, ahead=False, use_compact=False):
         ctx.sync()
         t = time.perf_counter()
         total = 0
         for k in range(args.steps):
             lay = layouts[k % n_layouts]
-            lay.reset(batches[k % 3], ahead=ahead)
+            if use_compact:
+                lay.reset_compact(*compact[k % 3], ahead=ahead)
+            else:
+                lay.reset(batches[k % 3], ahead=ahead)
             lay.fill(body)
             counters.zero_()
             lay.validate(body, results, counters)
@@ -72,6 +79,20 @@ def main():
         ms, gbs = run(n, ahead)
         print(f"  reset{'_ahead' if ahead else ''} + fill + validate per new batch, {n} layout(s): {1e3 * ms:8.2f} ms per batch = "
               f"{gbs:7.1f} GB/s generate+validate")
+    for n, ahead in ((1, False), (2, True)):
+        run(n, ahead, True)
+        ms, gbs = run(n, ahead, True)
+        print(f"  reset_compact{' ahead' if ahead else ''} + fill + validate per new batch, {n} layout(s): {1e3 * ms:8.2f} ms per batch = "
+              f"{gbs:7.1f} GB/s generate+validate")
+    call, done = [], []
+    for k in range(args.steps):
+        t = time.perf_counter()
+        layouts[0].reset_compact(*compact[k % 3])
+        call.append(time.perf_counter() - t)
+        ctx.sync()
+        done.append(time.perf_counter() - t)
+    print(f"  oval_layout_reset_compact, new table each time: call returns after {1e3 * np.median(call):.2f} ms, tables on "
+          f"the device after {1e3 * np.median(done):.2f} ms")
     lay = layouts[0]
     ctx.sync()
     t = time.perf_counter()
