@@ -130,6 +130,13 @@ void oval_pattern_set_lanes(int lanes, int blocking_sync);
  * a caller may poll for `spin_ns` nanoseconds before it sleeps (default 0).
  * Negative values keep the current setting. */
 void oval_pattern_set_wake_tuning(int fanout, int roots, int spin_ns);
+/* While micro-batching is on, a call that finds at most `callers` calls under way
+ * (itself included) still launches on its own: below that the hand-over to a lane
+ * costs more than a shared launch saves (default: the host's cores, at most 16; 0 = every call goes through
+ * the micro-batcher). */
+void oval_pattern_set_direct_callers(int callers);
+/* Launches and the jobs they carried since the library was loaded (a call that
+ * launched on its own counts as a launch of one job). */
 void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs);
 
 /* pattern.dump — pattern.go:182-206; and encoding/hex.Dump which feeds it.

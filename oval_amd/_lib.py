@@ -141,6 +141,7 @@ SIGNATURES = {
     "oval_pattern_set_batching": (None, [_int, _int, _sz]),
     "oval_pattern_set_lanes": (None, [_int, _int]),
     "oval_pattern_set_wake_tuning": (None, [_int, _int, _int]),
+    "oval_pattern_set_direct_callers": (None, [_int]),
     "oval_pattern_batching_stats": (None, [C.POINTER(_u64), C.POINTER(_u64)]),
     "oval_pattern_dump": (_sz, [_cp, _sz, _cp, _sz]),
     "oval_pattern_hex_dump": (_sz, [_vp, _sz, _cp, _sz]),

@@ -46,6 +46,12 @@ void set_wake_tree(int fanout, int roots);
 // How run() cuts a large batch: sub-batches of at most `chunk_bytes` (0 keeps the setting), `depth`
 // of them in flight (1..6, 0 keeps it).  Defaults 16 MiB and 3.  For benchmarks.
 void set_run_shape(size_t chunk_bytes, int depth);
+// A call that finds at most this many calls under way (itself included) launches on its own instead of
+// going through the micro-batcher (default: the host's cores, at most 16; 0 = always through the micro-batcher while it is on).
+void set_direct_max(int callers);
+// Whether a small batch on a polling lane signals its end through a flag its kernel writes to pinned
+// host memory (default) or through a stream event.  For benchmarks.
+void set_flag_completion(bool on);
 // A caller polls its wake word this long before it sleeps on it (default 0: sleep at once).
 void set_caller_spin(int ns);
 void stats(uint64_t* batches, uint64_t* jobs);

@@ -72,8 +72,12 @@ hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView
 // pinned host memory: n_val validate jobs (bodies at byte offsets into up_host,
 // one result each into results_host) and n_fill fill jobs (into down_host).
 // Descriptor offsets and lengths are the caller's responsibility: nothing is checked.
+// With `done_host` (pinned) the last workgroup to finish stores `done_seq` there
+// after everything the batch wrote is visible to the host; `done_count_dev` is a
+// zeroed u32 in device memory that the launch leaves zeroed.  NULL: no such signal.
 hipError_t launch_host_batch(hipStream_t s, const void* vdescs, uint32_t n_val, const void* fdescs, uint32_t n_fill,
-                             const void* up_host, void* down_host, oval_obj_result* results_host);
+                             const void* up_host, void* down_host, oval_obj_result* results_host,
+                             uint32_t* done_count_dev, uint32_t* done_host, uint32_t done_seq);
 
 // Looks up, once per GPU and with that GPU current, where the static scratch
 // array of launch_validate_noalloc lives in its memory.

@@ -611,9 +611,31 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 // the 16-byte result to host memory.  Descriptor offsets are byte offsets into
 // `up` (validate) or `down` (fill).
 // ---------------------------------------------------------------------------
+// Completion without an event: when `done_host` is given, every workgroup makes
+// its stores to host memory visible system-wide, counts itself in `done_count`
+// (device memory, zero between launches), and the last one to do so writes
+// `done_seq` to `done_host` (pinned).  The host then learns of the end of the
+// batch by reading its own memory, a few microseconds before the stream's
+// completion signal would have told it, and records no event per batch.
+__device__ __forceinline__ void host_batch_done(uint32_t* done_count, uint32_t* done_host, uint32_t done_seq)
+{
+    if (!done_host) return;
+    __threadfence_system();                                    // this thread's stores, host memory included
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t before = atomicAdd(done_count, 1u);
+        if (before == gridDim.x - 1u) {
+            __threadfence_system();                            // the other workgroups' stores come before the flag
+            __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done_host, done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void host_batch_kernel(sdesc_ptr vdescs, sdesc_ptr fdescs, uint32_t n_val,
                                                          const u32x4* __restrict__ up, u32x4* __restrict__ down,
-                                                         u32x4* __restrict__ results)
+                                                         u32x4* __restrict__ results, uint32_t* done_count,
+                                                         uint32_t* done_host, uint32_t done_seq)
 {
     __shared__ uint32_t part[4][4];                            // per wavefront: first, mask, cnt, sfirst
     const int lane = threadIdx.x & 63;
@@ -642,6 +664,7 @@ __global__ __launch_bounds__(256) void host_batch_kernel(sdesc_ptr vdescs, sdesc
                 __builtin_nontemporal_store(e, down + (size_t)g4 * 16u + (uint32_t)lane);
             }
         }
+        host_batch_done(done_count, done_host, done_seq);
         return;
     }
     const uint32_t zwmask = (j == 2) ? 0u : 0xFFFFFFFFu;       // pattern.go:172 "Skip the unix time area."
@@ -680,6 +703,7 @@ __global__ __launch_bounds__(256) void host_batch_kernel(sdesc_ptr vdescs, sdesc
         results[job] = (u32x4){mask, first != kNone ? first + w.ubias : kNone, cnt,
                                sfirst != kNone ? sfirst + w.ubias : kNone};
     }
+    host_batch_done(done_count, done_host, done_seq);
 }
 
 // counters += sum of the stripes; the stripes return to zero for the next pass.
@@ -911,12 +935,14 @@ hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView
 }
 
 hipError_t launch_host_batch(hipStream_t s, const void* vdescs, uint32_t n_val, const void* fdescs, uint32_t n_fill,
-                             const void* up_host, void* down_host, oval_obj_result* results_host)
+                             const void* up_host, void* down_host, oval_obj_result* results_host,
+                             uint32_t* done_count_dev, uint32_t* done_host, uint32_t done_seq)
 {
     if (n_val + n_fill == 0) return hipSuccess;
     host_batch_kernel<<<n_val + n_fill, 256, 0, s>>>((sdesc_ptr)vdescs, (sdesc_ptr)fdescs, n_val,
                                                      static_cast<const u32x4*>(up_host), static_cast<u32x4*>(down_host),
-                                                     reinterpret_cast<u32x4*>(results_host));
+                                                     reinterpret_cast<u32x4*>(results_host), done_count_dev, done_host,
+                                                     done_seq);
     return hipGetLastError();
 }
 

@@ -243,6 +243,10 @@ void SetBatchLanes(int lanes, int blockingSync) { engine::set_lanes(lanes, block
 
 void SetBatchShape(size_t chunkBytes, int depth) { engine::set_run_shape(chunkBytes, depth); }
 
+void SetFlagCompletion(bool on) { engine::set_flag_completion(on); }
+
+void SetDirectCallers(int callers) { engine::set_direct_max(callers); }
+
 void SetWakeTuning(int fanout, int roots, int spinNanos)
 {
     engine::set_wake_tree(fanout, roots);
@@ -1033,6 +1037,7 @@ void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes)
 
 void oval_pattern_set_lanes(int lanes, int blocking_sync) { oval::pattern::SetBatchLanes(lanes, blocking_sync); }
 
+void oval_pattern_set_direct_callers(int callers) { oval::pattern::SetDirectCallers(callers); }
 void oval_pattern_set_wake_tuning(int fanout, int roots, int spin_ns) { oval::pattern::SetWakeTuning(fanout, roots, spin_ns); }
 
 void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs)

@@ -183,6 +183,12 @@ void SetWakeTuning(int fanout, int roots, int spinNanos);
 // behind the other: at most `chunkBytes` each (0 keeps the setting; default 16 MiB), `depth` in flight
 // (0 keeps it; default 3).  For benchmarks.
 void SetBatchShape(size_t chunkBytes, int depth);
+// While micro-batching is on, a call that finds at most `callers` calls under way (itself included) still
+// launches on its own: below that the hand-over to a lane costs more than it saves (default: the host's cores, at most 16; 0 = never).
+void SetDirectCallers(int callers);
+// Whether a small batch signals its end through a flag its kernel writes to pinned host memory (default)
+// or through a stream event.  For benchmarks.
+void SetFlagCompletion(bool on);
 // Time the lane threads spent per phase since the last reset, summed over
 // lanes: [0] ns waiting for callers still copying their bodies in, [1] ns
 // enqueueing the batch, [2] ns waiting for the device, [3] ns publishing and

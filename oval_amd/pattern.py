@@ -200,6 +200,12 @@ def set_batching(enable: bool, window_us: int = 0, max_bytes: int = 64 << 20) ->
     _lib.lib().oval_pattern_set_batching(1 if enable else 0, window_us, max_bytes)
 
 
+def set_direct_callers(callers: int) -> None:
+    """While batching is on, a call that finds at most `callers` calls under way
+    launches on its own (default: the host's cores, at most 16; 0 = always through the micro-batcher)."""
+    _lib.lib().oval_pattern_set_direct_callers(callers)
+
+
 def set_lanes(lanes: int = 0, blocking_sync: int = -1) -> None:
     """Batches in flight at once / lane threads sleep instead of polling."""
     _lib.lib().oval_pattern_set_lanes(lanes, blocking_sync)

@@ -378,13 +378,15 @@ def test_idle_generated_bodies_do_not_starve_other_callers(oracle):
     held = []
     try:
         size = 3 << 20
-        for i in range(40):                                               # the engine has 18 slots
+        for i in range(48):                                               # the engine has 34 slots
             obj = Object("ov%010x" % i, size, i + 1)
             held.append((obj, pattern.GenerateParts(size, 7, "test-bucket", obj, 1 << 20)))
         pattern.set_batching(True, window_us=0)
         small = Object("ov00000000ff", 4096, 3)
-        for _ in range(50):
-            assert pattern.Generate(4096, 7, "test-bucket", small) == oracle.generate(4096, 7, "test-bucket", small.Key, 3, T0)
+        for direct in (0, 16):                                             # through the micro-batcher, then launching on its own
+            pattern.set_direct_callers(direct)
+            for _ in range(50):
+                assert pattern.Generate(4096, 7, "test-bucket", small) == oracle.generate(4096, 7, "test-bucket", small.Key, 3, T0)
         pattern.set_batching(False)
         big = Object("ov00000000fe", 1 << 20, 2)                          # takes a slot of its own
         pattern.Valid(7, "test-bucket", big, pattern.Generate(1 << 20, 7, "test-bucket", big))
@@ -393,6 +395,7 @@ def test_idle_generated_bodies_do_not_starve_other_callers(oracle):
             got = np.concatenate([parts.part(i) for i in range(len(parts))])
             assert np.array_equal(got, want)
     finally:
+        pattern.set_direct_callers(16)
         pattern.set_batching(False)
         for _, parts in held:
             parts.close()

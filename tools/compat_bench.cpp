@@ -6,7 +6,7 @@
 //   hipcc -O2 -std=c++17 -o build/compat_bench tools/compat_bench.cpp -Ioval_amd/csrc -Loval_amd -loval_hip -Wl,-rpath,$PWD/oval_amd -lpthread
 //
 //   compat_bench [seconds] [threads,threads,...] [lanes,lanes,...] [blocking 0|1|2 (2 = both)] [skip the unbatched run 0|1]
-//                [wake fan-out] [wake roots] [caller spin ns]
+//                [wake fan-out] [wake roots] [caller spin ns] [completion by flag 1|0] [direct below N callers]
 #include <sys/resource.h>
 
 #include <atomic>
@@ -107,6 +107,14 @@ int main(int argc, char** argv)
     if (pattern::Init(0) != 0) { std::fprintf(stderr, "init failed: %s\n", pattern::LastEngineError().c_str()); return 1; }
     pattern::Seed(1);
     pattern::SetWakeTuning(fanout, roots, spin);
+    if (argc > 10) {
+        pattern::SetDirectCallers(atoi(argv[10]));
+        std::printf("calls launch on their own while at most %d are under way\n", atoi(argv[10]));
+    }
+    if (argc > 9) {
+        pattern::SetFlagCompletion(atoi(argv[9]) != 0);
+        std::printf("small batches end by %s\n", atoi(argv[9]) ? "a flag their kernel writes to host memory" : "a stream event");
+    }
     if (argc > 6) std::printf("wake tree: fan-out %d, roots %d, caller spin %d ns (negative = default)\n", fanout, roots, spin);
     std::printf("host threads available to this process: %u\n", std::thread::hardware_concurrency());
     for (int n : threads) {
