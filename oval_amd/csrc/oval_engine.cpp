@@ -710,8 +710,45 @@ struct CallerCount {
 
 void set_direct_max(int callers) { g_direct_max.store(callers < 0 ? 0 : callers, std::memory_order_relaxed); }
 
+namespace {
+
+// One object of many megabytes in the caller's own (usually pageable) memory: the
+// host-memory entry points move it in 32 MiB slices through the slot context's
+// staging ring, pageable memory through pinned bounce slices filled on several
+// threads, with copies and kernel overlapped.  A slot of its own sized for the
+// whole body would pin that much memory and copy it one step after the other.
+constexpr size_t kLargeJobBytes = 8u << 20;
+
+void run_large(Job& job)
+{
+    Slot* s = acquire_slot();
+    reset_batch(*s);
+    int rc = ensure_slot(*s, 0, 0, 0);
+    if (!rc) {
+        oval_obj_desc d = job.desc;
+        d.body_offset = 0;
+        const uint64_t bytes = (uint64_t)d.n_units * kUnit;
+        if (job.is_fill) rc = oval_fill_batch_host(s->ctx, &d, 1, job.out, bytes);
+        else rc = oval_validate_batch_host(s->ctx, &d, 1, job.in, bytes, &job.res, nullptr);
+        if (rc) slot_fail(*s, rc);
+    }
+    if (rc) {
+        note_failure(*s);
+        job.failed = true;
+        job.err = s->err;
+        if (s->ctx) (void)oval_ctx_sync(s->ctx);
+    }
+    release_slot(s);
+}
+
+}  // namespace
+
 void execute(Job& job)
 {
+    if ((size_t)job.desc.n_units * kUnit >= kLargeJobBytes) {
+        run_large(job);
+        return;
+    }
     const CallerCount here;
     if (here.now <= direct_max()) {
         Job* p = &job;

@@ -767,11 +767,10 @@ Error Valid(int64_t workerID, const std::string& expectedBucketName, const objec
     if (nUnits <= 0) return Error::Nil();                    // the loop at :123 does not run
     if (nUnits > 0xFFFFFFF0ll) return Error::New("object size beyond the engine's 1 TiB limit");
     const size_t chunk_bytes = g_stream_chunk_bytes.load();
-    if ((uint64_t)nUnits * dataUnitSize > chunk_bytes)
-        return valid_streaming(workerID, bucket16, obj, reader, nUnits, chunk_bytes);
     const size_t want = (size_t)nUnits * dataUnitSize;
     size_t got = 0;
-    const uint8_t* body = reader.Contiguous(want, &got);     // a reader over memory lends its bytes
+    const uint8_t* body = reader.Contiguous(want, &got);     // a reader over memory lends its bytes, whatever their number
+    if (!body && want > chunk_bytes) return valid_streaming(workerID, bucket16, obj, reader, nUnits, chunk_bytes);
     if (!body) {
         thread_local std::vector<uint8_t> bounce;
         if (bounce.size() < want) bounce.resize(want);

@@ -446,3 +446,45 @@ def test_process_exits_cleanly_with_micro_batching_still_on():
     p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=110)
     assert p.returncode == 0, (p.returncode, p.stderr[-1500:])
     assert "generated 4096" in p.stdout
+
+
+def test_one_large_object_in_the_callers_memory(oracle):
+    """Generate of a body of many megabytes into the caller's own buffer and Valid
+    over bytes in memory go through the sliced host-memory path (no staging slot
+    of the body's size): the bytes and every verdict are the oracle's — clean, a
+    damaged first / middle / last unit, two damaged units, a body cut short inside
+    a unit and one cut at a unit's end."""
+    from oval_amd import pattern
+    from oval_amd.object import Object
+
+    pattern.init(0)
+    pattern.set_clock(T0)
+    try:
+        size = (40 << 20) + 768
+        obj = Object("ov00000000c1", size, 5)
+        body = pattern.Generate(size, 0x1234, "test-bucket", obj)
+        want = oracle.generate(size, 0x1234, "test-bucket", obj.Key, 5, T0)
+        assert body == want
+        pattern.Valid(0x1234, "test-bucket", obj, body)
+        n_units = size // 256
+        for units in ([0], [n_units // 2], [n_units - 1], [70000, 9]):
+            bad = bytearray(body)
+            for u in units:
+                bad[u * 256 + 17] ^= 0x20                                   # key field
+            bad = bytes(bad)
+            with pytest.raises(pattern.PatternError) as e:
+                pattern.Valid(0x1234, "test-bucket", obj, bad)
+            assert str(e.value) == oracle.valid(0x1234, "test-bucket", obj.Key, size, 5, bad)[2]
+        for cut in (size - 100, size - 256, (33 << 20) + 5):
+            short = body[:cut]
+            with pytest.raises(pattern.PatternError) as e:
+                pattern.Valid(0x1234, "test-bucket", obj, short)
+            assert str(e.value) == oracle.valid(0x1234, "test-bucket", obj.Key, size, 5, short)[2]
+        # damage wins over the short read that follows it (pattern.go:124-131)
+        both = bytearray(body[:size - 300]); both[5 * 256 + 28] ^= 1
+        with pytest.raises(pattern.PatternError) as e:
+            pattern.Valid(0x1234, "test-bucket", obj, bytes(both))
+        assert str(e.value) == oracle.valid(0x1234, "test-bucket", obj.Key, size, 5, bytes(both))[2]
+        assert "WriteCount is wrong" in str(e.value)
+    finally:
+        pattern.set_clock(-1)

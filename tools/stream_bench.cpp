@@ -137,6 +137,29 @@ int main(int argc, char** argv)
         std::printf("Valid(reader), %d-thread reader: %6.1f GB/s = %4.0f %% of H2D\n", threads, size * (double)reps / dt / 1e9,
                     100.0 * size * reps / dt / 1e9 / h2d);
     }
+    // Generate into the caller's own (pageable) buffer, and Valid over a reader that lends its bytes
+    // (bytes.NewReader over a []byte): what the Go binding's Generate / Valid do for a body in memory
+    {
+        std::vector<uint8_t> out(size);
+        double dg = 0, dv = 0;
+        for (int r = 0; r < reps + 1; ++r) {
+            double t = now_s();
+            const Error e = pattern::GenerateInto((int64_t)size, 0x561b, bucket, &obj, out.data());
+            const double a = now_s() - t;
+            if (!e.nil()) { std::fprintf(stderr, "GenerateInto: %s\n", e.msg.c_str()); return 5; }
+            pattern::BytesReader rd(out.data(), size);
+            t = now_s();
+            const Error v = pattern::Valid(0x561b, bucket, &obj, rd);
+            const double b = now_s() - t;
+            if (!v.nil()) { std::fprintf(stderr, "Valid(bytes): %s\n", v.msg.c_str()); return 5; }
+            if (r) { dg += a; dv += b; }
+        }
+        if (std::memcmp(out.data(), body.data(), size) != 0) { std::fprintf(stderr, "Generate and GenerateParts differ\n"); return 5; }
+        std::printf("Generate into pageable memory: %6.1f GB/s = %4.0f %% of D2H\n", size * (double)reps / dg / 1e9,
+                    100.0 * size * reps / dg / 1e9 / d2h);
+        std::printf("Valid(bytes reader), pageable: %6.1f GB/s = %4.0f %% of H2D\n", size * (double)reps / dv / 1e9,
+                    100.0 * size * reps / dv / 1e9 / h2d);
+    }
     // the reader alone, into pinned memory
     for (int threads : {1, rthreads}) {
         double dt = 0;
