@@ -472,6 +472,7 @@ void process_batch(Slot* s, uint64_t t, bool blocking, uint64_t* phase_ns)
 void lane_loop()
 {
     std::unique_lock<std::mutex> lk(g.mu);
+    (void)hipSetDevice(g.device);                                // a new thread starts on device 0
     for (;;) {
         g.lane_cv.wait(lk, [] {
             Slot* o = g.open.load(std::memory_order_relaxed);
