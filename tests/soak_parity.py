@@ -8,8 +8,8 @@ tiles, gaps from none to several tiles, parts of objects, names with white space
 at an edge, worker IDs outside uint32), fills it on the device and compares every
 byte with the oracle, then damages the bodies (bits, stale generations, foreign
 units, zeroed runs, damage on either side of chunk and tile seams) and compares
-results and counters.  Layouts are reused across trials through all three rebuild
-routes.  Stops at the first difference and prints the trial's seed.
+results and counters.  Layouts are reused across trials through all rebuild
+routes (in place, ahead, from compact records).  Stops at the first difference and prints the trial's seed.
 """
 import argparse
 import os
@@ -23,7 +23,7 @@ import torch  # noqa: E402
 
 from oracle import oracle  # noqa: E402
 from oval_amd import engine  # noqa: E402
-from oval_amd.batch import build_descs, make_keys, span_bytes  # noqa: E402
+from oval_amd.batch import build_descs, compact_from_descs, make_keys, span_bytes  # noqa: E402
 
 T0 = 1709558129112997
 
@@ -48,7 +48,14 @@ def trial(rng, ctx, layouts, k):
                         units * 256, first_units=(rng.integers(0, 1 << 24, size=n) if parts else 0), gap_bytes=gap)
     lay = layouts[k % len(layouts)]
     route = k % 3
-    lay.reset(descs, ahead=(route == 1))
+    if route == 2 and gap == 0 and not parts:
+        # whole objects back to back: the table can also be written on the device from compact records
+        segs, recs = compact_from_descs(descs)
+        lay.reset_compact(segs, recs, ahead=bool((k // 3) & 1))
+        if lay.read_descs().tobytes() != descs.tobytes():
+            raise AssertionError("the table written on the device differs from the host's")
+    else:
+        lay.reset(descs, ahead=(route == 1))
     nbytes = max(span_bytes(descs), 256) + 512
     body = torch.full((nbytes,), 0xEE, dtype=torch.uint8, device="cuda:0")
     lay.fill(body)
