@@ -825,16 +825,18 @@ void execute(Job& job)
     std::atomic<uint32_t>* word = &s->words[job.is_fill ? kSharedJobs + idx : idx].v;
     const uint32_t seq = word->load(std::memory_order_acquire);
     const size_t off = (size_t)((before >> ushift) & kUnitsMask) * kUnit;
-    if (t_jobs(before) == 0) {
-        // first job of the batch: a lane may be asleep (taking the lock orders
-        // this against a lane that has just found the slot empty)
-        { std::lock_guard<std::mutex> lk(g.mu); }
-        g.lane_cv.notify_one();
-    }
     job.desc.body_offset = off;
     (job.is_fill ? s->fdescs : s->vdescs)[idx] = job.desc;
     if (!job.is_fill) std::memcpy(s->up_host + off, job.in, bytes);
     s->written.fetch_add(1, std::memory_order_release);
+    if (t_jobs(before) == 0) {
+        // first job of the batch: a lane may be asleep (taking the lock orders
+        // this against a lane that has just found the slot empty).  Done after the
+        // job is written: between reservation and that point a caller holds up
+        // its whole batch, so nothing that can sleep or be preempted belongs there.
+        { std::lock_guard<std::mutex> lk(g.mu); }
+        g.lane_cv.notify_one();
+    }
     if (const int spin_ns = g_spin_ns.load(std::memory_order_relaxed)) {
         const uint64_t until = now_ns() + (uint64_t)spin_ns;
         while (word->load(std::memory_order_acquire) == seq && now_ns() < until) __builtin_ia32_pause();
