@@ -9,7 +9,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GO_DIR = os.path.join(ROOT, "go", "internal", "pattern")
 GO_FILE = os.path.join(GO_DIR, "pattern_hip.go")
-GO_FILES = sorted(os.path.join(GO_DIR, f) for f in os.listdir(GO_DIR) if f.endswith(".go"))
+GO_FILES = sorted(os.path.join(GO_DIR, f) for f in os.listdir(GO_DIR) if f.endswith(".go") and not f.endswith("_test.go"))
+GO_TEST_FILES = sorted(os.path.join(GO_DIR, f) for f in os.listdir(GO_DIR) if f.endswith("_test.go"))
 
 
 def _strip_c_comments(text):
@@ -104,3 +105,34 @@ def test_go_file_defines_the_reference_surface_and_has_no_placeholders():
     # the read callback has the type the header gives oval_read_fn
     hdr = _strip_c_comments(open(os.path.join(ROOT, "include", "oval_pattern.h")).read())
     assert re.search(r"typedef\s+size_t\s*\(\*oval_read_fn\)\(void\*\s*user,\s*uint8_t\*\s*p,\s*size_t\s+n\)", hdr)
+
+
+def test_go_tests_use_only_what_the_binding_defines():
+    """The Go tests of the MI355X build cannot be run here either: what can be
+    checked is that they carry the build tag, sit in the package, and name only
+    functions, methods and struct fields that the binding files define."""
+    assert GO_TEST_FILES
+    binding = "".join(open(f).read() for f in GO_FILES)
+    funcs = set(re.findall(r"^func (\w+)\(", binding, flags=re.M))
+    methods = set(re.findall(r"^func \(\w+ \*?\w+\) (\w+)\(", binding, flags=re.M))
+    for f in GO_TEST_FILES:
+        src = open(f).read()
+        assert src.startswith("//go:build ovalhip\n") and "\npackage pattern\n" in src, f
+        code = re.sub(r"//[^\n]*", "", src)
+        for name in ("GenerateBatch", "ValidBatch", "GenerateParts", "Generate", "Valid", "DecideSize"):
+            if re.search(r"\b%s\(" % name, code):
+                assert name in funcs, f"{name} is used by {os.path.basename(f)} but not defined by the binding"
+        for m in re.findall(r"\bparts\.(\w+)\(", code):
+            assert m in methods, f"Parts.{m} is not defined by the binding"
+        for struct, body in re.findall(r"\b(GenerateItem|ValidItem)\{([^}]*)\}", code):
+            decl = re.search(r"type %s struct \{(.*?)\n\}" % struct, binding, flags=re.S).group(1)
+            for field in re.findall(r"(\w+):", body):
+                assert re.search(r"^\s*%s\s" % field, decl, flags=re.M), f"{struct} has no field {field}"
+        # every import is used and every used package imported (the mistakes a compiler would refuse first)
+        imports = re.findall(r'^\t"([\w/.]+)"$', src, flags=re.M)
+        for imp in imports:
+            pkg = imp.rsplit("/", 1)[-1]
+            assert re.search(r"\b%s\." % pkg, code), f"{os.path.basename(f)} imports {imp} without using it"
+        for pkg in ("bytes", "io", "strings", "sync", "object", "testing"):
+            if re.search(r"\b%s\.\w" % pkg, code):
+                assert any(i.rsplit("/", 1)[-1] == pkg for i in imports), f"{os.path.basename(f)} uses {pkg} without importing it"
