@@ -438,10 +438,20 @@ void wake_children(Slot* s, uint32_t d)
     for (uint32_t c = r + f * d, k = 0; k < f && c < n; ++c, ++k) wake_job(s, c);
 }
 
+// Everything is read from the slot before the first wake: once the last root has
+// been woken the batch's callers may all be through, and the slot released,
+// reopened and described anew, before this function returns.
 void wake_roots(Slot* s)
 {
-    const uint32_t n = s->n_val + s->n_fill;
-    for (uint32_t c = 0; c < (uint32_t)s->wake_roots && c < n; ++c) wake_job(s, c);
+    const uint32_t n_val = s->n_val, n = s->n_val + s->n_fill;
+    uint32_t roots = (uint32_t)s->wake_roots;
+    if (roots > n) roots = n;
+    WakeWord* const words = s->words.get();
+    for (uint32_t c = 0; c < roots; ++c) {
+        std::atomic<uint32_t>* w = &words[c < n_val ? c : kSharedJobs + (c - n_val)].v;
+        w->fetch_add(1, std::memory_order_release);
+        futex_wake(w, 1);
+    }
 }
 
 // The batch of a slot whose ticket was closed at `t`: waits for the callers
