@@ -750,24 +750,34 @@ int oval_layout_reset_compact(oval_ctx* ctx, oval_layout* l, const oval_obj_segm
     if (next != n_obj)
         return fail(OVAL_E_LAYOUT, "the segments cover %llu records, the table holds %llu", (unsigned long long)next,
                     (unsigned long long)n_obj);
-    std::vector<uint64_t> seg_units(n_segs, 0);
-    std::vector<uint32_t> seg_max_id(n_segs, 0);
-    TaskPool::get().run(n_segs, [&](size_t k) {
-        uint64_t units = 0;
-        uint32_t max_id = 0;
-        const oval_obj_rec* r = recs + segs[k].first_obj;
-        for (uint32_t i = 0; i < segs[k].n_obj; ++i) {
-            units += r[i].n_units;
-            if (r[i].obj_id > max_id) max_id = r[i].obj_id;
+    // units and key range, record range by record range on the helper threads (a table may be one segment)
+    constexpr uint64_t kRecsPerTask = 128u << 10;
+    const uint64_t n_tasks = (n_obj + kRecsPerTask - 1) / kRecsPerTask;
+    std::vector<uint64_t> task_units(n_tasks, 0), task_bad(n_tasks, UINT64_MAX);
+    TaskPool::get().run(n_tasks, [&](size_t t) {
+        const uint64_t begin = t * kRecsPerTask, end = begin + kRecsPerTask < n_obj ? begin + kRecsPerTask : n_obj;
+        uint64_t lo = 0, hi = n_segs - 1;                        // the segment that holds record `begin`
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi + 1) / 2;
+            if (segs[mid].first_obj <= begin) lo = mid; else hi = mid - 1;
         }
-        seg_units[k] = units;
-        seg_max_id[k] = max_id;
+        uint64_t k = lo, units = 0;
+        for (uint64_t i = begin; i < end; ++i) {
+            while (i >= (uint64_t)segs[k].first_obj + segs[k].n_obj) ++k;
+            units += recs[i].n_units;
+            if (segs[k].key_id_base + recs[i].obj_id >= (1ull << 40) && task_bad[t] == UINT64_MAX) task_bad[t] = i;
+        }
+        task_units[t] = units;
     });
-    for (uint64_t k = 0; k < n_segs; ++k) {
-        if (segs[k].key_id_base + seg_max_id[k] >= (1ull << 40) || segs[k].key_id_base >= (1ull << 40))
-            return fail(OVAL_E_LAYOUT, "segment %llu: object ID %llu needs more than 10 hex digits, the key would exceed 12 bytes",
-                        (unsigned long long)k, (unsigned long long)(segs[k].key_id_base + seg_max_id[k]));
-        sh.total_units += seg_units[k];
+    for (uint64_t k = 0; k < n_segs; ++k)
+        if (segs[k].key_id_base >= (1ull << 40))
+            return fail(OVAL_E_LAYOUT, "segment %llu: key range base %llu needs more than 10 hex digits", (unsigned long long)k,
+                        (unsigned long long)segs[k].key_id_base);
+    for (uint64_t t = 0; t < n_tasks; ++t) {
+        if (task_bad[t] != UINT64_MAX)
+            return fail(OVAL_E_LAYOUT, "record %llu: its object ID needs more than 10 hex digits, the key would exceed 12 bytes",
+                        (unsigned long long)task_bad[t]);
+        sh.total_units += task_units[t];
     }
     if (sh.total_units >= 0xFFFFFF00ull)
         return fail(OVAL_E_LAYOUT, "batch spans %llu bytes; the limit is just under 1 TiB",
