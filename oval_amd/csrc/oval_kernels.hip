@@ -632,10 +632,43 @@ __device__ __forceinline__ void host_batch_done(uint32_t* done_count, uint32_t* 
     }
 }
 
+// The work of one workgroup of a host batch: job `job` (a validate job if
+// is_val), described by `r`.
+__device__ __forceinline__ void host_batch_job(const WRaw& r, bool is_val, uint32_t job, const u32x4* __restrict__ up,
+                                               u32x4* __restrict__ down, u32x4* __restrict__ results,
+                                               uint32_t* done_count, uint32_t* done_host, uint32_t done_seq);
+
 __global__ __launch_bounds__(256) void host_batch_kernel(sdesc_ptr vdescs, sdesc_ptr fdescs, uint32_t n_val,
                                                          const u32x4* __restrict__ up, u32x4* __restrict__ down,
                                                          u32x4* __restrict__ results, uint32_t* done_count,
                                                          uint32_t* done_host, uint32_t done_seq)
+{
+    const bool is_val = blockIdx.x < n_val;
+    const uint32_t job = is_val ? blockIdx.x : blockIdx.x - n_val;
+    sdesc_ptr dp = (is_val ? vdescs : fdescs) + 4u * job;
+    WRaw r;
+    r.o = 0;
+    r.d0 = dp[0]; r.d1 = dp[1]; r.d2 = dp[2]; r.d3 = dp[3];
+    host_batch_job(r, is_val, job, up, down, results, done_count, done_host, done_seq);
+}
+
+// A batch of one job, its descriptor in the kernel arguments: one trip over
+// PCIe less before the body can be touched (a call that launches on its own
+// waits for every one of them).
+__global__ __launch_bounds__(256) void host_one_kernel(u32x4 d0, u32x4 d1, u32x4 d2, u32x4 d3, uint32_t is_val,
+                                                       const u32x4* __restrict__ up, u32x4* __restrict__ down,
+                                                       u32x4* __restrict__ results, uint32_t* done_count,
+                                                       uint32_t* done_host, uint32_t done_seq)
+{
+    WRaw r;
+    r.o = 0;
+    r.d0 = d0; r.d1 = d1; r.d2 = d2; r.d3 = d3;
+    host_batch_job(r, is_val != 0u, 0u, up, down, results, done_count, done_host, done_seq);
+}
+
+__device__ __forceinline__ void host_batch_job(const WRaw& r, bool is_val, uint32_t job, const u32x4* __restrict__ up,
+                                               u32x4* __restrict__ down, u32x4* __restrict__ results,
+                                               uint32_t* done_count, uint32_t* done_host, uint32_t done_seq)
 {
     __shared__ uint32_t part[4][4];                            // per wavefront: first, mask, cnt, sfirst
     const int lane = threadIdx.x & 63;
@@ -645,12 +678,6 @@ __global__ __launch_bounds__(256) void host_batch_kernel(sdesc_ptr vdescs, sdesc
     const uint32_t gmul = (j == 2) ? 256u : 0u;
     const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
                         filler_dword(4u * j + 3u)};
-    const bool is_val = blockIdx.x < n_val;
-    const uint32_t job = is_val ? blockIdx.x : blockIdx.x - n_val;
-    sdesc_ptr dp = (is_val ? vdescs : fdescs) + 4u * job;
-    WRaw r;
-    r.o = 0;
-    r.d0 = dp[0]; r.d1 = dp[1]; r.d2 = dp[2]; r.d3 = dp[3];
     WObj w;
     w_activate(r, 1u, w);
     const u32x4 tmpl = w_lane_template(w, j, cpat);
@@ -939,6 +966,13 @@ hipError_t launch_host_batch(hipStream_t s, const void* vdescs, uint32_t n_val, 
                              uint32_t* done_count_dev, uint32_t* done_host, uint32_t done_seq)
 {
     if (n_val + n_fill == 0) return hipSuccess;
+    if (n_val + n_fill == 1) {
+        const u32x4* d = static_cast<const u32x4*>(n_val ? vdescs : fdescs);   // pinned host memory: read here
+        host_one_kernel<<<1, 256, 0, s>>>(d[0], d[1], d[2], d[3], n_val, static_cast<const u32x4*>(up_host),
+                                          static_cast<u32x4*>(down_host), reinterpret_cast<u32x4*>(results_host),
+                                          done_count_dev, done_host, done_seq);
+        return hipGetLastError();
+    }
     host_batch_kernel<<<n_val + n_fill, 256, 0, s>>>((sdesc_ptr)vdescs, (sdesc_ptr)fdescs, n_val,
                                                      static_cast<const u32x4*>(up_host), static_cast<u32x4*>(down_host),
                                                      reinterpret_cast<u32x4*>(results_host), done_count_dev, done_host,
