@@ -32,6 +32,7 @@
 // Stores are non-temporal: a fill that leaves its lines dirty in L2 / Infinity
 // Cache makes the validate pass that follows pay for their write-back (measured:
 // validate 6.9 -> 5.3 TB/s behind a plain-store fill).
+#include <cstring>
 #include <mutex>
 
 #include "oval_kernels.h"
@@ -666,6 +667,24 @@ __global__ __launch_bounds__(256) void host_one_kernel(u32x4 d0, u32x4 d1, u32x4
     host_batch_job(r, is_val != 0u, 0u, up, down, results, done_count, done_host, done_seq);
 }
 
+// A batch of up to kArgJobs jobs, its descriptors in the kernel arguments
+// (validate jobs first, then fill jobs): the same trip saved for every workgroup.
+constexpr uint32_t kArgJobs = 32;
+struct ArgDescs { u32x4 q[kArgJobs * 4u]; };                    // 2 KiB of the 4 KiB a launch may carry (48 jobs measured no better)
+
+__global__ __launch_bounds__(256) void host_args_kernel(ArgDescs descs, uint32_t n_val, const u32x4* __restrict__ up,
+                                                        u32x4* __restrict__ down, u32x4* __restrict__ results,
+                                                        uint32_t* done_count, uint32_t* done_host, uint32_t done_seq)
+{
+    const bool is_val = blockIdx.x < n_val;
+    const uint32_t job = is_val ? blockIdx.x : blockIdx.x - n_val;
+    WRaw r;
+    r.o = 0;
+    r.d0 = descs.q[4u * blockIdx.x]; r.d1 = descs.q[4u * blockIdx.x + 1u];
+    r.d2 = descs.q[4u * blockIdx.x + 2u]; r.d3 = descs.q[4u * blockIdx.x + 3u];
+    host_batch_job(r, is_val, job, up, down, results, done_count, done_host, done_seq);
+}
+
 __device__ __forceinline__ void host_batch_job(const WRaw& r, bool is_val, uint32_t job, const u32x4* __restrict__ up,
                                                u32x4* __restrict__ down, u32x4* __restrict__ results,
                                                uint32_t* done_count, uint32_t* done_host, uint32_t done_seq)
@@ -971,6 +990,16 @@ hipError_t launch_host_batch(hipStream_t s, const void* vdescs, uint32_t n_val, 
         host_one_kernel<<<1, 256, 0, s>>>(d[0], d[1], d[2], d[3], n_val, static_cast<const u32x4*>(up_host),
                                           static_cast<u32x4*>(down_host), reinterpret_cast<u32x4*>(results_host),
                                           done_count_dev, done_host, done_seq);
+        return hipGetLastError();
+    }
+    if (n_val + n_fill <= kArgJobs) {
+        ArgDescs a;                                             // descriptors are pinned host memory: read here
+        std::memcpy(a.q, vdescs, (size_t)n_val * 64u);
+        std::memcpy(a.q + 4u * n_val, fdescs, (size_t)n_fill * 64u);
+        host_args_kernel<<<n_val + n_fill, 256, 0, s>>>(a, n_val, static_cast<const u32x4*>(up_host),
+                                                        static_cast<u32x4*>(down_host),
+                                                        reinterpret_cast<u32x4*>(results_host), done_count_dev, done_host,
+                                                        done_seq);
         return hipGetLastError();
     }
     host_batch_kernel<<<n_val + n_fill, 256, 0, s>>>((sdesc_ptr)vdescs, (sdesc_ptr)fdescs, n_val,
