@@ -1101,6 +1101,15 @@ int host_layout_for(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, c
 
 }  // namespace
 
+int oval_internal_pinned_alloc_coherent(oval_ctx* ctx, size_t bytes, void** hptr_out)
+{
+    if (!ctx || !hptr_out) return fail(OVAL_E_INVALID, "NULL argument");
+    *hptr_out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipHostMalloc(hptr_out, bytes ? bytes : 1, hipHostMallocCoherent | hipHostMallocMapped));
+    return OVAL_OK;
+}
+
 void oval_internal_parallel_for(size_t n, const std::function<void(size_t)>& fn) { TaskPool::get().run(n, fn); }
 
 void oval_internal_parallel_copy(void* dst, const void* src, size_t n)

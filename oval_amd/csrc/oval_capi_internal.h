@@ -26,3 +26,7 @@ uint64_t oval_internal_host_slice_bytes(void);
 // fn(0) .. fn(n - 1) on the library's helper threads and the calling thread;
 // returns when all have run.  One such run at a time per process.
 void oval_internal_parallel_for(size_t n, const std::function<void(size_t)>& fn);
+
+// oval_pinned_alloc with host coherence asked for explicitly (whatever the process environment makes the
+// default): memory a kernel writes and the host reads while that kernel is still running.
+int oval_internal_pinned_alloc_coherent(oval_ctx* ctx, size_t bytes, void** hptr_out);

@@ -201,7 +201,7 @@ int ensure_slot(Slot& s, size_t up, size_t down, size_t jobs)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done_block, hipEventDisableTiming | hipEventBlockingSync);
         for (int h = 0; h < 2 && e == hipSuccess; ++h) e = hipEventCreateWithFlags(&s.half_ev[h], hipEventDisableTiming);
         if (e != hipSuccess) return hip_fail(s, e, "hipEventCreate");
-        if ((rc = oval_pinned_alloc(s.ctx, 64, (void**)&s.done_flag))) return slot_fail(s, rc);
+        if ((rc = oval_internal_pinned_alloc_coherent(s.ctx, 64, (void**)&s.done_flag))) return slot_fail(s, rc);
         if ((rc = oval_dev_alloc(s.ctx, 64, (void**)&s.done_count_dev))) return slot_fail(s, rc);
         *s.done_flag = 0;
         s.done_seq = 0;
@@ -212,7 +212,7 @@ int ensure_slot(Slot& s, size_t up, size_t down, size_t jobs)
         if (s.up_dev) oval_dev_free(s.ctx, s.up_dev);
         s.up_host = nullptr; s.up_dev = nullptr; s.up_cap = 0;
         const size_t cap = round_cap(up);
-        if ((rc = oval_pinned_alloc(s.ctx, cap, (void**)&s.up_host))) return slot_fail(s, rc);
+        if ((rc = oval_internal_pinned_alloc_coherent(s.ctx, cap, (void**)&s.up_host))) return slot_fail(s, rc);
         if ((rc = oval_dev_alloc(s.ctx, cap, &s.up_dev))) return slot_fail(s, rc);
         s.up_cap = cap;
     }
@@ -221,7 +221,7 @@ int ensure_slot(Slot& s, size_t up, size_t down, size_t jobs)
         if (s.down_dev) oval_dev_free(s.ctx, s.down_dev);
         s.down_host = nullptr; s.down_dev = nullptr; s.down_cap = 0;
         const size_t cap = round_cap(down);
-        if ((rc = oval_pinned_alloc(s.ctx, cap, (void**)&s.down_host))) return slot_fail(s, rc);
+        if ((rc = oval_internal_pinned_alloc_coherent(s.ctx, cap, (void**)&s.down_host))) return slot_fail(s, rc);
         if ((rc = oval_dev_alloc(s.ctx, cap, &s.down_dev))) return slot_fail(s, rc);
         s.down_cap = cap;
     }
@@ -230,11 +230,11 @@ int ensure_slot(Slot& s, size_t up, size_t down, size_t jobs)
         if (s.res_dev) oval_dev_free(s.ctx, s.res_dev);
         s.res_host = nullptr; s.res_dev = nullptr; s.job_cap = 0;
         const size_t cap = jobs < 64 ? 64 : jobs + jobs / 4;
-        if ((rc = oval_pinned_alloc(s.ctx, cap * sizeof(oval_obj_result), (void**)&s.res_host))) return slot_fail(s, rc);
+        if ((rc = oval_internal_pinned_alloc_coherent(s.ctx, cap * sizeof(oval_obj_result), (void**)&s.res_host))) return slot_fail(s, rc);
         if ((rc = oval_dev_alloc(s.ctx, cap * sizeof(oval_obj_result), (void**)&s.res_dev))) return slot_fail(s, rc);
         if (s.fdescs) oval_pinned_free(s.ctx, s.fdescs);
         s.fdescs = nullptr; s.vdescs = nullptr;
-        if ((rc = oval_pinned_alloc(s.ctx, 2 * cap * sizeof(oval_obj_desc), (void**)&s.fdescs))) return slot_fail(s, rc);
+        if ((rc = oval_internal_pinned_alloc_coherent(s.ctx, 2 * cap * sizeof(oval_obj_desc), (void**)&s.fdescs))) return slot_fail(s, rc);
         s.vdescs = s.fdescs + cap;
         s.job_cap = cap;
         if (jobs >= kSharedJobs && !s.words) s.words.reset(new WakeWord[2 * kSharedJobs]);
