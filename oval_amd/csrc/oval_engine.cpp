@@ -21,6 +21,20 @@
 // a tree (see kWakeFanout); each copies its own body out of the pinned buffer,
 // and the last one returns the slot to the free list.
 // The pipeline lock is taken a few times per batch, never per job.
+//
+// Two things keep a call short when few are under way.  A call that finds no
+// more calls inside execute() than the host has cores (at most 16) skips all of
+// the above and launches a batch of one in a slot of its own: the hand-over to a
+// lane costs two sleeps and two wake-ups, more than a launch.  And a small
+// batch on a polling lane (or such a batch of one) ends without a stream event:
+// the kernel's last workgroup stores the batch's sequence number to a pinned
+// word once everything the batch wrote has reached host memory, and the host
+// reads its own memory.
+//
+// Large work goes other ways: a batch form (run) beyond 16 MiB travels as
+// sub-batches through up to three slots with its host copies on helper threads,
+// and a single object of 8 MiB or more takes the sliced host-memory path of the
+// C ABI on a slot's context (run_large).
 #include "oval_engine.hpp"
 
 #include <hip/hip_runtime.h>
