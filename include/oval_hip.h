@@ -130,6 +130,14 @@ typedef struct oval_layout oval_layout;  /* device-resident descriptor table */
 const char* oval_last_error(void);            /* thread-local, never NULL     */
 const char* oval_version(void);
 int oval_device_count(int* n_out);
+/* How long a host thread inside this library waits for the device before it
+ * gives up: the host-memory entry points below and everything behind
+ * oval_pattern.h fail with OVAL_E_HIP ("the device did not finish within the
+ * time limit") instead of waiting for ever on a kernel or copy that never
+ * ends.  Default 30000; 0 = no limit.  oval_ctx_sync and oval_timer_elapsed_ms
+ * are the caller's own waits and stay unbounded.  The reference has no
+ * counterpart (its pattern code cannot hang). */
+int oval_set_device_timeout_ms(uint64_t ms);
 
 /* ---- context ------------------------------------------------------------
  * A context binds one device and one stream.  `stream` is a hipStream_t cast
@@ -320,6 +328,9 @@ int oval_comm_unique_id(uint8_t* id_out);
  * context's device current. */
 int oval_comm_create(oval_ctx* ctx, int n_ranks, int rank, const uint8_t* id, oval_comm** out);
 int oval_comm_destroy(oval_comm* comm);
+/* Size of the communicator and this rank's place in it, as RCCL reports them
+ * (ncclCommCount, ncclCommUserRank).  Either output may be NULL. */
+int oval_comm_info(const oval_comm* comm, int* n_ranks_out, int* rank_out);
 /* counters_dev[0..n) = sum over all ranks, in place, asynchronously on the
  * context's stream (ncclAllReduce, ncclUint64, ncclSum). */
 int oval_allreduce_counters(oval_ctx* ctx, oval_comm* comm, uint64_t* counters_dev, size_t n);

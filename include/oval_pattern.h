@@ -23,9 +23,23 @@
 extern "C" {
 #endif
 
-/* Creates the process-wide engine on `device_id` (idempotent). */
+/* Creates the process-wide engine on `device_id` (idempotent).  With
+ * OVAL_HIP_ENGINES=N in the environment: N engines on devices device_id,
+ * device_id + 1, ... modulo the visible GPUs ("all": one per visible GPU). */
 int oval_pattern_init(int device_id);
+/* One engine per entry of devices[0..n) (1 <= n <= 16; a GPU may be named more
+ * than once).  Every call is routed by its worker ID modulo the engine count:
+ * the workers of a process carry consecutive IDs
+ * (internal/runner/runner.go:110-113), so they spread evenly and all objects of
+ * a worker meet the same GPU.  The first init call of a process decides. */
+int oval_pattern_init_engines(const int* devices, int n);
+int oval_pattern_engine_count(void);
 void oval_pattern_shutdown(void);
+/* oval_set_device_timeout_ms (oval_hip.h) under this header's naming: how long
+ * a call waits for the device before it fails with a negative status ("device
+ * did not finish the batch"); the staging slot of such a batch is never used
+ * again, other calls go on.  Default 30000 ms; 0 = no limit. */
+void oval_pattern_set_device_timeout(uint64_t ms);
 
 /* time.Now().UnixMicro() as Generate sees it (pattern.go:103-104).  A value
  * >= 0 pins the clock (every unit of a call gets this value); < 0 returns to
@@ -135,6 +149,16 @@ void oval_pattern_set_wake_tuning(int fanout, int roots, int spin_ns);
  * costs more than a shared launch saves (default: the host's cores, at most 16; 0 = every call goes through
  * the micro-batcher). */
 void oval_pattern_set_direct_callers(int callers);
+/* How long a caller of a shared launch polls for its outcome before it sleeps
+ * (-1, the default: about as long as shared launches have lately taken; 0:
+ * never) and how many callers may poll at the same time (-1: a quarter of the
+ * cores that calls launching on their own may use). */
+void oval_pattern_set_caller_spin(int spin_ns, int max_spinners);
+/* Test hook: the next n small launches never report their end, as on a device
+ * that hangs; their calls fail after the device time limit and their staging
+ * slots are set aside (counted by oval_pattern_quarantined_slots). */
+void oval_pattern_test_lose_flags(int n);
+int oval_pattern_quarantined_slots(void);
 /* Launches and the jobs they carried since the library was loaded (a call that
  * launched on its own counts as a launch of one job). */
 void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs);

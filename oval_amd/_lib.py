@@ -79,6 +79,7 @@ SIGNATURES = {
     "oval_last_error": (_cp, []),
     "oval_version": (_cp, []),
     "oval_device_count": (_int, [C.POINTER(_int)]),
+    "oval_set_device_timeout_ms": (_int, [_u64]),
     "oval_ctx_create": (_int, [_int, _vp, _pp]),
     "oval_ctx_destroy": (_int, [_vp]),
     "oval_ctx_sync": (_int, [_vp]),
@@ -109,6 +110,7 @@ SIGNATURES = {
     "oval_comm_unique_id": (_int, [_vp]),
     "oval_comm_create": (_int, [_vp, _int, _int, _vp, _pp]),
     "oval_comm_destroy": (_int, [_vp]),
+    "oval_comm_info": (_int, [_vp, C.POINTER(_int), C.POINTER(_int)]),
     "oval_allreduce_counters": (_int, [_vp, _vp, _vp, _sz]),
     "oval_gather_first_bad": (_int, [_vp, _vp, _u64, _vp]),
     "oval_allreduce_first_bad": (_int, [_vp, _vp, _vp, _sz]),
@@ -119,6 +121,12 @@ SIGNATURES = {
     "oval_timer_elapsed_ms": (_int, [_vp, C.POINTER(C.c_float)]),
     # oval_pattern.h
     "oval_pattern_init": (_int, [_int]),
+    "oval_pattern_init_engines": (_int, [C.POINTER(_int), _int]),
+    "oval_pattern_engine_count": (_int, []),
+    "oval_pattern_set_device_timeout": (None, [_u64]),
+    "oval_pattern_set_caller_spin": (None, [_int, _int]),
+    "oval_pattern_test_lose_flags": (None, [_int]),
+    "oval_pattern_quarantined_slots": (_int, []),
     "oval_pattern_shutdown": (None, []),
     "oval_pattern_set_clock": (None, [_i64]),
     "oval_pattern_seed": (None, [_u64]),

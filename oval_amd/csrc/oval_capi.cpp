@@ -4,6 +4,7 @@
 // through the gfx950 kernels, and a process without a usable device gets
 // OVAL_E_NODEVICE / OVAL_E_HIP, never a silent fallback.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -11,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -123,6 +125,79 @@ void oval_internal_parallel_copy(void* dst, const void* src, size_t n);   // mem
 int oval_internal_ctx_device(const oval_ctx* ctx) { return ctx->device; }
 hipStream_t oval_internal_ctx_stream(const oval_ctx* ctx) { return ctx->stream; }
 
+// ---- waits on the device that end ------------------------------------------------
+// hipEventSynchronize / hipStreamSynchronize never return while the device keeps
+// answering "not ready": a kernel that never finishes would take every host thread
+// that waits for it along.  The host-memory entry points and the pipeline behind
+// the pattern API wait through these two instead: they poll, back off, and give up
+// after the process-wide limit (oval_set_device_timeout_ms, 30 s by default) with
+// hipErrorNotReady and the thread's timed-out mark set.
+namespace {
+std::atomic<uint64_t> g_device_timeout_ms{30000};
+thread_local bool g_wait_timed_out = false;
+
+uint64_t mono_ns()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+template <class Query>
+hipError_t bounded_wait(const Query& query, bool sleepy)
+{
+    uint64_t t0 = 0;
+    for (uint32_t polls = 0;; ++polls) {
+        const hipError_t q = query();
+        if (q != hipErrorNotReady) return q;
+        (void)hipGetLastError();                                 // "not ready" is not an error to keep
+        if (!sleepy && (polls & 63u) != 63u) {
+            __builtin_ia32_pause();
+            continue;
+        }
+        const uint64_t now = mono_ns();
+        if (!t0) t0 = now;
+        const uint64_t waited = now - t0, limit = g_device_timeout_ms.load(std::memory_order_relaxed) * 1000000ull;
+        if (limit && waited > limit) {
+            g_wait_timed_out = true;
+            return hipErrorNotReady;
+        }
+        // short waits spin; a wait that has lasted milliseconds gives the core away between looks
+        if (sleepy || waited > 50000000ull) {
+            const timespec nap = {0, sleepy ? 50000 : 200000};
+            nanosleep(&nap, nullptr);
+        } else if (waited > 2000000ull) {
+            sched_yield();
+        }
+    }
+}
+}  // namespace
+
+hipError_t oval_internal_wait_event(hipEvent_t ev, bool sleepy)
+{
+    return bounded_wait([ev] { return hipEventQuery(ev); }, sleepy);
+}
+
+hipError_t oval_internal_wait_stream(hipStream_t stream)
+{
+    return bounded_wait([stream] { return hipStreamQuery(stream); }, false);
+}
+
+bool oval_internal_wait_timed_out(bool clear)
+{
+    const bool t = g_wait_timed_out;
+    if (clear) g_wait_timed_out = false;
+    return t;
+}
+
+uint64_t oval_internal_device_timeout_ns(void) { return g_device_timeout_ms.load(std::memory_order_relaxed) * 1000000ull; }
+
+const char* oval_internal_wait_error(hipError_t e)
+{
+    return e == hipErrorNotReady ? "the device did not finish within the time limit (oval_set_device_timeout_ms)"
+                                 : hipGetErrorString(e);
+}
+
 namespace {
 
 #define HIP_TRY(expr)                                                                    \
@@ -177,6 +252,12 @@ extern "C" {
 const char* oval_last_error(void) { return g_err.c_str(); }
 
 const char* oval_version(void) { return "oval_hip 0.1 (gfx950)"; }
+
+int oval_set_device_timeout_ms(uint64_t ms)
+{
+    g_device_timeout_ms.store(ms, std::memory_order_relaxed);
+    return OVAL_OK;
+}
 
 int oval_device_count(int* n_out)
 {
@@ -274,6 +355,23 @@ int oval_ctx_sync(oval_ctx* ctx)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return OVAL_OK;
 }
+
+}  // extern "C"
+
+// Waits for the context's main stream AND its two copy streams: the host-memory entry points leave slice
+// copies on the latter, which oval_ctx_sync does not cover.
+int oval_internal_ctx_sync_all(oval_ctx* ctx)
+{
+    if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
+    const hipError_t e1 = oval_internal_wait_stream(ctx->stream);
+    const hipError_t e2 = oval_internal_wait_stream(ctx->copy_stream);
+    const hipError_t e3 = oval_internal_wait_stream(ctx->copy_stream2);
+    const hipError_t e = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3;
+    if (e != hipSuccess) return fail(OVAL_E_HIP, "waiting for the context's streams: %s", oval_internal_wait_error(e));
+    return OVAL_OK;
+}
+
+extern "C" {
 
 int oval_ctx_stream(oval_ctx* ctx, void** stream_out)
 {
@@ -1156,7 +1254,7 @@ int oval_internal_fill_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t 
     Drain drains[kSlots];
     auto drain = [&](uint32_t k) {                              // pageable: bounce slot -> caller's memory
         Drain& d = drains[k % kSlots];
-        hipError_t de = hipEventSynchronize(ctx->bounce_ev[k % kSlots]);
+        hipError_t de = oval_internal_wait_event(ctx->bounce_ev[k % kSlots], false);
         if (de == hipSuccess) copy_segments(d.segs.data(), d.segs.size());
         return de;
     };
@@ -1201,12 +1299,12 @@ int oval_internal_fill_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t 
     if (!pinned)
         for (uint32_t q = k > kLag ? k - kLag : 0; q < k && e == hipSuccess; ++q) e = drain(q);
     if (wait || e != hipSuccess) {
-        const hipError_t e1 = hipStreamSynchronize(ctx->stream);
-        const hipError_t e2 = hipStreamSynchronize(ctx->copy_stream);
-        const hipError_t e3 = hipStreamSynchronize(ctx->copy_stream2);
+        const hipError_t e1 = oval_internal_wait_stream(ctx->stream);
+        const hipError_t e2 = oval_internal_wait_stream(ctx->copy_stream);
+        const hipError_t e3 = oval_internal_wait_stream(ctx->copy_stream2);
         if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3;
     }
-    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "fill_batch_host: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "fill_batch_host: %s", oval_internal_wait_error(e));
     return OVAL_OK;
 }
 
@@ -1250,7 +1348,7 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
         hipError_t ue = hipSuccess;
         if (!pinned) {
             // the bounce slot's previous slice must have left for the device
-            if (k >= kSlots) ue = hipEventSynchronize(ctx->bounce_ev[slot]);
+            if (k >= kSlots) ue = oval_internal_wait_event(ctx->bounce_ev[slot], false);
             if (ue != hipSuccess) return ue;
             segs.clear();
             add_segs(segs, bounce_slot(ctx, slot), src, b1 - b0);
@@ -1270,15 +1368,18 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
     oval_layout* l = nullptr;
     int rc = e == hipSuccess ? host_layout_for(ctx, descs, n_obj, body_host, body_bytes, &l) : OVAL_OK;
     if (rc || (l && l->span_bytes != span)) {
-        (void)hipStreamSynchronize(ctx->copy_stream);
-        (void)hipStreamSynchronize(ctx->copy_stream2);
+        (void)oval_internal_wait_stream(ctx->copy_stream);
+        (void)oval_internal_wait_stream(ctx->copy_stream2);
         return rc ? rc : fail(OVAL_E_LAYOUT, "descriptor table does not end where its last entry does");
     }
     if (e == hipSuccess && (n_obj > ctx->host_res_cap || !ctx->host_res_dev)) {
-        if (ctx->host_res_dev) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->host_res_dev); }
+        if (ctx->host_res_dev) {
+            e = oval_internal_wait_stream(ctx->stream);          // a pass may still write the old array
+            if (e == hipSuccess) (void)hipFree(ctx->host_res_dev);   // (one that never ends keeps it: leaked, not freed under it)
+        }
         ctx->host_res_dev = nullptr; ctx->host_res_cap = 0;
         const uint64_t cap = n_obj < 1024 ? 1024 : n_obj + n_obj / 8;
-        e = hipMalloc((void**)&ctx->host_res_dev, cap * sizeof(oval_obj_result));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->host_res_dev, cap * sizeof(oval_obj_result));
         if (e == hipSuccess) ctx->host_res_cap = cap;
     }
     if (e == hipSuccess && !ctx->host_cnt_dev) e = hipMalloc((void**)&ctx->host_cnt_dev, OVAL_NUM_COUNTERS * 8);
@@ -1304,11 +1405,11 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
         e = hipMemcpyAsync(results_host, res_dev, n_obj * sizeof(oval_obj_result), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && counters_host)
         e = hipMemcpyAsync(counters_host, cnt_dev, OVAL_NUM_COUNTERS * 8, hipMemcpyDeviceToHost, ctx->stream);
-    const hipError_t e1 = hipStreamSynchronize(ctx->stream);
-    const hipError_t e2 = hipStreamSynchronize(ctx->copy_stream);
-    const hipError_t e3 = hipStreamSynchronize(ctx->copy_stream2);
+    const hipError_t e1 = oval_internal_wait_stream(ctx->stream);
+    const hipError_t e2 = oval_internal_wait_stream(ctx->copy_stream);
+    const hipError_t e3 = oval_internal_wait_stream(ctx->copy_stream2);
     if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3;
-    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "validate_batch_host: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "validate_batch_host: %s", oval_internal_wait_error(e));
     return OVAL_OK;
 }
 

@@ -11,6 +11,18 @@
 int oval_internal_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int oval_internal_ctx_device(const oval_ctx* ctx);
 hipStream_t oval_internal_ctx_stream(const oval_ctx* ctx);
+// oval_ctx_sync over the main stream and both copy streams of the context (the host-memory entry points
+// leave slice copies on the latter).
+int oval_internal_ctx_sync_all(oval_ctx* ctx);
+
+// hipEventSynchronize / hipStreamSynchronize that give up: they poll, back off, and after the process-wide
+// limit (oval_set_device_timeout_ms) return hipErrorNotReady with the calling thread's timed-out mark set.
+// `sleepy`: nap between looks from the start (the waiter has nothing better to do than leave its core).
+hipError_t oval_internal_wait_event(hipEvent_t ev, bool sleepy);
+hipError_t oval_internal_wait_stream(hipStream_t stream);
+bool oval_internal_wait_timed_out(bool clear);          // this thread's mark (and reset)
+uint64_t oval_internal_device_timeout_ns(void);         // 0 = no limit
+const char* oval_internal_wait_error(hipError_t e);     // hipGetErrorString, with the time limit spelt out
 
 // The host-memory fill behind oval_fill_batch_host, optionally without the final
 // wait: landed[k] (then body_host must be pinned and n_landed >= the number of

@@ -32,6 +32,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;       // optional: oval_comm_info
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     bool ok = false;
     char why[256] = {0};
 };
@@ -54,6 +56,8 @@ Rccl& rccl()
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.handle, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.handle, "ncclCommUserRank"));
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
         if (!r.ok) std::snprintf(r.why, sizeof r.why, "librccl lacks one of the five entry points used here");
     });
@@ -117,6 +121,23 @@ int oval_comm_destroy(oval_comm* comm)
     const ncclResult_t e = rccl().CommDestroy(comm->comm);
     delete comm;
     return e == ncclSuccess ? OVAL_OK : rccl_fail("ncclCommDestroy", e);
+}
+
+int oval_comm_info(const oval_comm* comm, int* n_ranks_out, int* rank_out)
+{
+    if (!comm) return oval_internal_fail(OVAL_E_INVALID, "comm is NULL");
+    Rccl& r = rccl();
+    int n = comm->n_ranks, me = comm->rank;
+    if (r.CommCount && r.CommUserRank) {
+        // what the communicator itself says, not what it was asked for
+        ncclResult_t e = r.CommCount(comm->comm, &n);
+        if (e != ncclSuccess) return rccl_fail("ncclCommCount", e);
+        e = r.CommUserRank(comm->comm, &me);
+        if (e != ncclSuccess) return rccl_fail("ncclCommUserRank", e);
+    }
+    if (n_ranks_out) *n_ranks_out = n;
+    if (rank_out) *rank_out = me;
+    return OVAL_OK;
 }
 
 int oval_allreduce_counters(oval_ctx* ctx, oval_comm* comm, uint64_t* counters_dev, size_t n)

@@ -31,6 +31,15 @@
 // word once everything the batch wrote has reached host memory, and the host
 // reads its own memory.
 //
+// One engine (everything above) per GPU of the process: a call is routed by its
+// worker ID, so a worker's objects always meet the same device, and engines share
+// nothing but the host's cores.
+//
+// Every wait on the device ends: waits poll with a wall-clock limit
+// (oval_set_device_timeout_ms), and a slot whose batch did not finish in time is
+// set aside for good (its memory may still be written by the device) while the
+// other slots go on working.
+//
 // Large work goes other ways: a batch form (run) beyond 16 MiB travels as
 // sub-batches through up to three slots with its host copies on helper threads,
 // and a single object of 8 MiB or more takes the sliced host-memory path of the
@@ -47,9 +56,11 @@
 #include <chrono>
 #include <climits>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -91,7 +102,12 @@ void futex_wake(std::atomic<uint32_t>* a, int n)
 // batch of 100 jobs), during which that lane submits nothing.
 constexpr int kWakeFanout = 4, kWakeRoots = 1;
 std::atomic<int> g_wake_fanout{kWakeFanout}, g_wake_roots{kWakeRoots};   // set_wake_tree(): benchmarks only
-std::atomic<int> g_spin_ns{0};            // how long a caller polls its word before it sleeps on it
+// How long a caller polls its wake word before it sleeps on it: -1 = as long as batches have lately taken
+// on the device (while fewer callers than g_spin_budget are polling), 0 = never, > 0 = that many ns.
+std::atomic<int> g_spin_ns{-1};
+std::atomic<int> g_spin_budget{-1};        // callers that may poll at once; -1: a quarter of the host's cores
+std::atomic<int> g_spinners{0};
+std::atomic<int> g_test_lose_flags{0};     // test hook: that many coming flag batches never see their flag
 constexpr uint32_t kFlagMaxJobs = 24;
 std::atomic<bool> g_flag_completion{true};   // small batches on polling lanes end by a flag in host memory, not by an event
 
@@ -113,11 +129,18 @@ inline uint32_t t_val_jobs(uint64_t t) { return (uint32_t)((t >> kValJobsShift) 
 inline uint32_t t_fill_jobs(uint64_t t) { return (uint32_t)((t >> kFillJobsShift) & kJobsMask); }
 inline uint32_t t_jobs(uint64_t t) { return t_val_jobs(t) + t_fill_jobs(t); }
 
+// A wake word counts completions in steps of two; its lowest bit says that the job's caller is asleep on
+// it (so whoever completes the job knows whether a system call is needed to wake it).
 struct alignas(64) WakeWord {
     std::atomic<uint32_t> v{0};
 };
 
+struct Pipeline;
+
 struct Slot {
+    Pipeline* pipe = nullptr;             // the engine this slot belongs to
+    bool quarantined = false;             // its batch never finished: the device may still write its memory
+    bool lose_flag = false;               // test hook: the batch in flight was given a flag word nobody reads
     oval_ctx* ctx = nullptr;
     oval_layout* fill_layout = nullptr;
     oval_layout* val_layout = nullptr;
@@ -174,14 +197,59 @@ struct Pipeline {
     uint64_t batches = 0, jobs = 0;
     uint64_t prof[kProfileWords] = {};    // lane time by phase, ns (lane_profile)
     std::string err;
-    std::mutex ctl_mu;                    // serialises set_batching / shutdown (held across the joins)
+    int index = 0;                        // which engine of the process this is
+    int quarantined = 0;                  // slots set aside for good (see Slot::quarantined)
+    uint64_t batch_ns = 20000;            // how long a shared batch has lately taken from submit to completion (lanes write, callers read)
+    // generated bodies that still hold a slot of this engine, and its idle pinned buffers
+    std::mutex parts_mu;
+    std::vector<struct Parts*> live_parts;
+    std::mutex pool_mu;
+    std::vector<struct PinnedBuf> pool_idle;
+    size_t pool_idle_bytes = 0;
 };
 
-// Never destroyed: a process that exits while micro-batching is on still has lane threads asleep in
-// lane_loop, and destroying their std::thread objects (or the mutex they wait on) at exit would abort it.
-Pipeline& g = *new Pipeline;
+struct PinnedBuf {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+};
 
-void pool_drop_all();                     // pinned buffers of the generated-parts pool (below)
+// Engines are never destroyed: a process that exits while micro-batching is on still has lane threads
+// asleep in lane_loop, and destroying their std::thread objects (or the mutex they wait on) at exit would
+// abort it.
+constexpr int kMaxEngines = 16;
+Pipeline* g_engines[kMaxEngines] = {};
+std::atomic<int> g_n_engines{0};
+std::mutex g_engines_mu;                  // engine table, set_batching / shutdown (held across the joins)
+struct Config {                           // what set_lanes / set_batching said, for engines made later
+    int n_lanes = 2, blocking = 0, window_us = 0;
+    bool enabled = false;
+} g_cfg;
+
+void ensure_inited_locked(Pipeline& g);
+
+// The engine table with at least one engine in it (a process that never called init gets one on device 0).
+int engines()
+{
+    int n = g_n_engines.load(std::memory_order_acquire);
+    if (n) return n;
+    std::lock_guard<std::mutex> lk(g_engines_mu);
+    n = g_n_engines.load(std::memory_order_relaxed);
+    if (n) return n;
+    if (!g_engines[0]) g_engines[0] = new Pipeline;
+    g_engines[0]->index = 0;
+    g_n_engines.store(1, std::memory_order_release);
+    return 1;
+}
+
+// Calls are spread by worker ID (internal/runner/runner.go:110-113 stamps consecutive IDs on the workers
+// of a process): all objects of a worker meet one device.
+Pipeline& engine_for(uint32_t route)
+{
+    const int n = engines();
+    return *g_engines[n == 1 ? 0 : (int)(route % (uint32_t)n)];
+}
+
+void pool_drop_all(Pipeline& g);          // pinned buffers of the generated-parts pool (below)
 
 int slot_fail(Slot& s, int rc)
 {
@@ -208,16 +276,17 @@ int ensure_slot(Slot& s, size_t up, size_t down, size_t jobs)
 {
     int rc;
     if (!s.ctx) {
-        if ((rc = oval_ctx_create(g.device, nullptr, &s.ctx))) return slot_fail(s, rc);
+        if ((rc = oval_ctx_create(s.pipe->device, nullptr, &s.ctx))) return slot_fail(s, rc);
         if ((rc = oval_layout_create(s.ctx, nullptr, 0, &s.fill_layout))) return slot_fail(s, rc);
         if ((rc = oval_layout_create(s.ctx, nullptr, 0, &s.val_layout))) return slot_fail(s, rc);
         hipError_t e = hipEventCreateWithFlags(&s.done_spin, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done_block, hipEventDisableTiming | hipEventBlockingSync);
         for (int h = 0; h < 2 && e == hipSuccess; ++h) e = hipEventCreateWithFlags(&s.half_ev[h], hipEventDisableTiming);
         if (e != hipSuccess) return hip_fail(s, e, "hipEventCreate");
-        if ((rc = oval_internal_pinned_alloc_coherent(s.ctx, 64, (void**)&s.done_flag))) return slot_fail(s, rc);
+        if ((rc = oval_internal_pinned_alloc_coherent(s.ctx, 128, (void**)&s.done_flag))) return slot_fail(s, rc);
         if ((rc = oval_dev_alloc(s.ctx, 64, (void**)&s.done_count_dev))) return slot_fail(s, rc);
-        *s.done_flag = 0;
+        s.done_flag[0] = 0;
+        s.done_flag[16] = 0;                                     // a second cache line: where a lost flag goes (test hook)
         s.done_seq = 0;
         if ((e = hipMemset(s.done_count_dev, 0, 64)) != hipSuccess) return hip_fail(s, e, "hipMemset");
     }
@@ -251,15 +320,20 @@ int ensure_slot(Slot& s, size_t up, size_t down, size_t jobs)
         if ((rc = oval_internal_pinned_alloc_coherent(s.ctx, 2 * cap * sizeof(oval_obj_desc), (void**)&s.fdescs))) return slot_fail(s, rc);
         s.vdescs = s.fdescs + cap;
         s.job_cap = cap;
-        if (jobs >= kSharedJobs && !s.words) s.words.reset(new WakeWord[2 * kSharedJobs]);
     }
+    // The wake words belong to shared use, not to a capacity: a slot whose arrays grew for a batch form
+    // (any job count) may become the open slot later without growing again.
+    if (jobs >= kSharedJobs && !s.words) s.words.reset(new WakeWord[2 * kSharedJobs]);
     return OVAL_OK;
 }
 
 void destroy_slot(Slot& s)
 {
-    if (!s.ctx) return;
-    oval_ctx_sync(s.ctx);
+    if (!s.ctx || s.quarantined) return;                         // what the device may still write is never freed
+    if (oval_internal_ctx_sync_all(s.ctx)) {
+        s.quarantined = true;
+        return;
+    }
     if (s.up_host) oval_pinned_free(s.ctx, s.up_host);
     if (s.up_dev) oval_dev_free(s.ctx, s.up_dev);
     if (s.down_host) oval_pinned_free(s.ctx, s.down_host);
@@ -298,16 +372,21 @@ int submit(Slot& s, bool blocking)
 {
     int rc;
     hipStream_t stream = oval_internal_ctx_stream(s.ctx);
+    (void)hipSetDevice(s.pipe->device);                          // a caller's thread may last have used another engine's GPU
     s.by_flag = false;
+    s.lose_flag = false;
     if (s.max_job_bytes <= kSharedJobMax && s.val_bytes + s.fill_bytes <= kZeroCopyMax) {
         // (every workgroup pays a system-wide release of its stores for the flag: with a few dozen of them
         // that costs the device more than the event saves the host — 38 jobs: 22.5 against 19.0 us)
         const uint32_t n_jobs = s.n_val + s.n_fill;
         const bool flag = !blocking && g_flag_completion.load(std::memory_order_relaxed) && n_jobs != 0 && n_jobs <= kFlagMaxJobs;
         if (flag) ++s.done_seq;
+        if (flag && g_test_lose_flags.load(std::memory_order_relaxed) > 0 &&
+            g_test_lose_flags.fetch_sub(1, std::memory_order_relaxed) > 0)
+            s.lose_flag = true;                                  // the kernel reports to a word wait_done does not read
         const hipError_t e = launch_host_batch(stream, s.vdescs, s.n_val, s.fdescs, s.n_fill, s.up_host, s.down_host,
                                                s.res_host, flag ? s.done_count_dev : nullptr,
-                                               flag ? s.done_flag : nullptr, s.done_seq);
+                                               flag ? (s.lose_flag ? s.done_flag + 16 : s.done_flag) : nullptr, s.done_seq);
         if (e != hipSuccess) return hip_fail(s, e, "host batch launch");
         if (flag) {
             s.by_flag = true;
@@ -331,18 +410,35 @@ int submit(Slot& s, bool blocking)
     return OVAL_OK;
 }
 
+// The slot's batch did not finish within the time limit: whatever it was given (pinned and device
+// buffers, result arrays) may still be written by the device, so the slot never carries work again.
+int slot_timed_out(Slot& s, const char* what)
+{
+    s.quarantined = true;
+    s.failed = true;
+    s.err = std::string("device did not finish the batch (") + what + ") within " +
+            std::to_string(oval_internal_device_timeout_ns() / 1000000ull) + " ms; its staging slot is set aside";
+    return OVAL_E_HIP;
+}
+
 int wait_done(Slot& s, bool blocking)
 {
     if (s.by_flag) {
         s.by_flag = false;
         volatile uint32_t* flag = s.done_flag;
+        uint64_t t0 = 0;
         for (uint64_t spins = 0; *flag != s.done_seq; ++spins) {
             __builtin_ia32_pause();
-            if ((spins & 0xFFFFu) == 0xFFFFu) {
-                // every few milliseconds: a stream that has gone idle or bad without the flag would spin here for ever
-                const hipError_t q = hipStreamQuery(oval_internal_ctx_stream(s.ctx));
+            if ((spins & 0x3FFFu) == 0x3FFFu) {
+                // every millisecond or so: the time limit, and a stream that has gone idle or bad without the flag
+                const uint64_t now = now_ns(), limit = oval_internal_device_timeout_ns();
+                if (!t0) t0 = now;
+                if (limit && now - t0 > limit) return slot_timed_out(s, "completion flag");
+                const hipError_t q = s.lose_flag ? hipErrorNotReady : hipStreamQuery(oval_internal_ctx_stream(s.ctx));
                 if (q == hipSuccess) {
                     if (*flag == s.done_seq) break;
+                    // the workgroup count of a batch that ended early must not carry over into the next one
+                    (void)hipMemset(s.done_count_dev, 0, 64);
                     return hip_fail(s, hipErrorUnknown, "the batch ended without its completion flag");
                 }
                 if (q != hipErrorNotReady) return hip_fail(s, q, "hipStreamQuery");
@@ -357,64 +453,113 @@ int wait_done(Slot& s, bool blocking)
         }
         return OVAL_OK;
     }
-    const hipError_t e = hipEventSynchronize(blocking ? s.done_block : s.done_spin);
-    if (e != hipSuccess) return hip_fail(s, e, "hipEventSynchronize");
+    (void)oval_internal_wait_timed_out(true);
+    const hipError_t e = oval_internal_wait_event(blocking ? s.done_block : s.done_spin, blocking);
+    if (e != hipSuccess) {
+        if (oval_internal_wait_timed_out(true)) return slot_timed_out(s, "completion event");
+        return hip_fail(s, e, "waiting for the batch");
+    }
     return OVAL_OK;
 }
 
-void note_failure(const Slot& s)
+// After a failure: everything the slot's context still has in flight, with the time limit.
+void settle_slot(Slot& s)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    g.err = s.err;
+    if (!s.ctx || s.quarantined) return;
+    (void)oval_internal_wait_timed_out(true);
+    if (oval_internal_ctx_sync_all(s.ctx) && oval_internal_wait_timed_out(true)) s.quarantined = true;
 }
 
-void ensure_inited_locked()
+std::mutex g_err_mu;
+std::string g_last_err;                   // text of the most recent engine failure, whichever engine
+
+void note_failure(const Slot& s)
+{
+    {
+        std::lock_guard<std::mutex> lk(s.pipe->mu);
+        s.pipe->err = s.err;
+    }
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_last_err = s.err;
+}
+
+void ensure_inited_locked(Pipeline& g)
 {
     if (g.inited) return;
-    for (Slot& s : g.slots) g.free_slots.push_back(&s);
+    for (Slot& s : g.slots) {
+        s.pipe = &g;
+        g.free_slots.push_back(&s);
+    }
     g.inited = true;
+}
+
+bool shared_ready(const Slot& s) { return s.ctx && s.up_cap >= kSharedBytes && s.down_cap >= kSharedBytes && s.job_cap >= kSharedJobs && s.words; }
+
+// Takes a slot off the free list (mu held, list not empty).  Shared use wants one whose 2 x 16 MiB of
+// pinned and device memory exist already; exclusive use leaves those to the micro-batcher when it can,
+// so that only a handful of slots ever grow to that size.
+Slot* pop_free_locked(Pipeline& g, bool for_shared)
+{
+    size_t pick = g.free_slots.size() - 1;
+    for (size_t i = g.free_slots.size(); i-- > 0;)
+        if (shared_ready(*g.free_slots[i]) == for_shared) {
+            pick = i;
+            break;
+        }
+    Slot* s = g.free_slots[pick];
+    g.free_slots.erase(g.free_slots.begin() + (long)pick);
+    return s;
 }
 
 // Generated bodies (parts_open) keep their slot until their last slice has landed, but nobody is told
 // when that happens: whoever finds no slot free looks whether one of them is done (defined below).
-bool reap_finished_parts();
+bool reap_finished_parts(Pipeline& g);
 
-// A free slot for the caller's exclusive use.
-Slot* acquire_slot()
+// A free slot for the caller's exclusive use; NULL once every slot of the engine has been lost to a
+// device that does not answer.
+Slot* acquire_slot(Pipeline& g)
 {
     std::unique_lock<std::mutex> lk(g.mu);
-    ensure_inited_locked();
+    ensure_inited_locked(g);
     while (g.free_slots.empty()) {
+        if (g.quarantined == kSlots) return nullptr;
         lk.unlock();
-        const bool reaped = reap_finished_parts();
+        const bool reaped = reap_finished_parts(g);
         lk.lock();
         if (reaped || !g.free_slots.empty()) continue;
         g.slot_waiters++;
         g.slot_cv.wait_for(lk, std::chrono::microseconds(200));   // a landed body frees its slot without a notify
         g.slot_waiters--;
     }
-    Slot* s = g.free_slots.back();
-    g.free_slots.pop_back();
-    return s;
+    return pop_free_locked(g, false);
 }
 
 // A free slot if there is one right now.
-Slot* try_acquire_slot()
+Slot* try_acquire_slot(Pipeline& g)
 {
     std::lock_guard<std::mutex> lk(g.mu);
-    ensure_inited_locked();
+    ensure_inited_locked(g);
     if (g.free_slots.empty()) return nullptr;
-    Slot* s = g.free_slots.back();
-    g.free_slots.pop_back();
-    return s;
+    return pop_free_locked(g, false);
 }
 
-// Makes `c` the open slot (mu held).  Its first shared use allocates its buffers.
-bool install_open_locked(Slot* c)
+const char* const kNoSlots = "every staging slot of this engine has been set aside after device time-outs";
+
+// Makes `c` (off the free list, owned by the caller) the open slot; `lk` holds mu on entry and on return.
+// The first shared use of a slot allocates 2 x 16 MiB of pinned and as much device memory, which takes
+// milliseconds: mu is dropped for that, and if somebody else has installed an open slot meanwhile (or
+// batching has ended) `c` is not installed.  False: `c` is still the caller's.
+bool install_open(std::unique_lock<std::mutex>& lk, Pipeline& g, Slot* c)
 {
-    if (ensure_slot(*c, kSharedBytes, kSharedBytes, kSharedJobs)) {
-        g.err = c->err;
-        return false;
+    if (!shared_ready(*c)) {
+        lk.unlock();
+        const int rc = ensure_slot(*c, kSharedBytes, kSharedBytes, kSharedJobs);
+        lk.lock();
+        if (rc) {
+            g.err = c->err;
+            return false;
+        }
+        if (g.open.load(std::memory_order_relaxed) || !g.enabled.load(std::memory_order_relaxed) || g.stop) return false;
     }
     reset_batch(*c);
     c->ticket.store(0, std::memory_order_relaxed);
@@ -424,23 +569,35 @@ bool install_open_locked(Slot* c)
 
 void release_slot(Slot* s)
 {
+    Pipeline& g = *s->pipe;
     bool wake;
     {
-        std::lock_guard<std::mutex> lk(g.mu);
-        // callers may be waiting for an open slot because every slot was busy
-        if (!(g.enabled.load(std::memory_order_relaxed) && !g.stop && !g.open.load(std::memory_order_relaxed) &&
-              install_open_locked(s)))
+        std::unique_lock<std::mutex> lk(g.mu);
+        if (s->quarantined) {
+            g.quarantined++;                                     // never on the free list again
+        } else if (!(g.enabled.load(std::memory_order_relaxed) && !g.stop && !g.open.load(std::memory_order_relaxed) &&
+                     shared_ready(*s) && install_open(lk, g, s))) {
+            // (callers may be waiting for an open slot because every slot was busy: a slot that is ready for
+            // shared use becomes the open one at once)
             g.free_slots.push_back(s);
+        }
         wake = g.slot_waiters > 0;
     }
     if (wake) g.slot_cv.notify_all();
 }
 
+// Completes a wake word: the next even value, and a system call only if its caller sleeps on it.
+void complete_word(std::atomic<uint32_t>* w)
+{
+    uint32_t old = w->load(std::memory_order_relaxed);
+    while (!w->compare_exchange_weak(old, (old | 1u) + 1u, std::memory_order_release, std::memory_order_relaxed)) {
+    }
+    if (old & 1u) futex_wake(w, 1);
+}
+
 void wake_job(Slot* s, uint32_t d)
 {
-    std::atomic<uint32_t>* w = &s->words[d < s->n_val ? d : kSharedJobs + (d - s->n_val)].v;
-    w->fetch_add(1, std::memory_order_release);
-    futex_wake(w, 1);
+    complete_word(&s->words[d < s->n_val ? d : kSharedJobs + (d - s->n_val)].v);
 }
 
 // Job d wakes jobs roots + fanout d ... roots + fanout d + fanout - 1; jobs 0 ... roots - 1 are woken
@@ -461,11 +618,7 @@ void wake_roots(Slot* s)
     uint32_t roots = (uint32_t)s->wake_roots;
     if (roots > n) roots = n;
     WakeWord* const words = s->words.get();
-    for (uint32_t c = 0; c < roots; ++c) {
-        std::atomic<uint32_t>* w = &words[c < n_val ? c : kSharedJobs + (c - n_val)].v;
-        w->fetch_add(1, std::memory_order_release);
-        futex_wake(w, 1);
-    }
+    for (uint32_t c = 0; c < roots; ++c) complete_word(&words[c < n_val ? c : kSharedJobs + (c - n_val)].v);
 }
 
 // The batch of a slot whose ticket was closed at `t`: waits for the callers
@@ -487,9 +640,10 @@ void process_batch(Slot* s, uint64_t t, bool blocking, uint64_t* phase_ns)
     int rc = submit(*s, blocking);
     const uint64_t t2 = now_ns();
     if (!rc) rc = wait_done(*s, blocking);
-    else (void)oval_ctx_sync(s->ctx);                            // whatever was enqueued before the failure
+    else settle_slot(*s);                                        // whatever was enqueued before the failure
     const uint64_t t3 = now_ns();
     if (rc) note_failure(*s);
+    else s->pipe->batch_ns = (3 * s->pipe->batch_ns + (t3 - t1)) / 4;   // (lanes race on this estimate; any of their values will do)
     s->readers.store((int)n_jobs, std::memory_order_relaxed);
     wake_roots(s);
     if (phase_ns) {
@@ -497,12 +651,13 @@ void process_batch(Slot* s, uint64_t t, bool blocking, uint64_t* phase_ns)
     }
 }
 
-void lane_loop()
+void lane_loop(Pipeline* pipe)
 {
+    Pipeline& g = *pipe;
     std::unique_lock<std::mutex> lk(g.mu);
     (void)hipSetDevice(g.device);                                // a new thread starts on device 0
     for (;;) {
-        g.lane_cv.wait(lk, [] {
+        g.lane_cv.wait(lk, [&g] {
             Slot* o = g.open.load(std::memory_order_relaxed);
             return g.stop || (o && t_jobs(o->ticket.load(std::memory_order_acquire)) != 0);
         });
@@ -520,9 +675,8 @@ void lane_loop()
         // the successor first, so that callers always find an open slot; then close this one
         g.open.store(nullptr, std::memory_order_release);
         if (!g.free_slots.empty()) {
-            Slot* f = g.free_slots.back();
-            g.free_slots.pop_back();
-            if (!install_open_locked(f)) g.free_slots.push_back(f);
+            Slot* f = pop_free_locked(g, true);
+            if (!install_open(lk, g, f)) g.free_slots.push_back(f);
         }
         const uint64_t t = s->ticket.fetch_or(kClosed, std::memory_order_acq_rel);
         const bool blocking = g.blocking != 0;
@@ -544,27 +698,75 @@ void lane_loop()
 
 }  // namespace
 
+namespace {
+void start_lanes_locked(Pipeline& g);     // (g_engines_mu held) below, with set_batching
+
+bool engine_idle(Pipeline& g)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    ensure_inited_locked(g);
+    for (const Slot& s : g.slots)
+        if (s.ctx && !s.quarantined) return false;               // (slots set aside for good keep what they hold)
+    return true;
+}
+}  // namespace
+
+int init_engines(const int* devices, int n)
+{
+    if (n < 1 || n > kMaxEngines || !devices) return oval_internal_fail(OVAL_E_INVALID, "1 to %d engines", kMaxEngines);
+    {
+        std::lock_guard<std::mutex> lk(g_engines_mu);
+        // the first call decides: engines that hold device resources stay as they are
+        bool fresh = true;
+        const int have = g_n_engines.load(std::memory_order_relaxed);
+        for (int k = 0; k < have; ++k) fresh &= engine_idle(*g_engines[k]);
+        if (fresh && !g_cfg.enabled) {
+            for (int k = 0; k < n; ++k) {
+                if (!g_engines[k]) g_engines[k] = new Pipeline;
+                g_engines[k]->index = k;
+                g_engines[k]->device = devices[k];
+                std::lock_guard<std::mutex> elk(g_engines[k]->mu);
+                ensure_inited_locked(*g_engines[k]);
+            }
+            g_n_engines.store(n, std::memory_order_release);
+        }
+    }
+    // one slot's context per engine proves its device is usable
+    const int have = engines();
+    for (int k = 0; k < have; ++k) {
+        Slot* s = acquire_slot(*g_engines[k]);
+        if (!s) return oval_internal_fail(OVAL_E_HIP, "%s", kNoSlots);
+        const int rc = ensure_slot(*s, 0, 0, 0);
+        if (rc) note_failure(*s);
+        release_slot(s);
+        if (rc) return rc;
+    }
+    return OVAL_OK;
+}
+
 int init(int device)
 {
-    {
-        std::lock_guard<std::mutex> lk(g.mu);
-        ensure_inited_locked();
-        bool any = false;
-        for (const Slot& s : g.slots) any |= s.ctx != nullptr;
-        if (!any) g.device = device;                             // the first call decides
+    // OVAL_HIP_ENGINES=N: N engines on devices device, device + 1, ... (modulo the visible GPUs, so that
+    // a one-GPU box can run two engines on its one device); "all": one per visible GPU
+    int n = 1, n_dev = 1;
+    if (const char* e = std::getenv("OVAL_HIP_ENGINES")) {
+        (void)oval_device_count(&n_dev);
+        if (n_dev < 1) n_dev = 1;
+        n = std::strcmp(e, "all") == 0 ? n_dev : std::atoi(e);
+        if (n < 1) n = 1;
+        if (n > kMaxEngines) n = kMaxEngines;
     }
-    // one slot's context proves the device is usable
-    Slot* s = acquire_slot();
-    const int rc = ensure_slot(*s, 0, 0, 0);
-    if (rc) note_failure(*s);
-    release_slot(s);
-    return rc;
+    int devices[kMaxEngines];
+    for (int k = 0; k < n; ++k) devices[k] = n == 1 ? device : (device + k) % n_dev;
+    return init_engines(devices, n);
 }
+
+int engine_count() { return engines(); }
 
 std::string last_error()
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    return g.err;
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    return g_last_err;
 }
 
 namespace {
@@ -643,7 +845,7 @@ void sub_start(SubBatch& b)
             }
         });
     b.rc = submit(*s, false);
-    if (b.rc) (void)oval_ctx_sync(s->ctx);                       // whatever was enqueued before the failure
+    if (b.rc) settle_slot(*s);                                   // whatever was enqueued before the failure
 }
 
 // Waits for the sub-batch, hands bodies and verdicts to the jobs and gives the slot back.
@@ -672,9 +874,41 @@ void sub_finish(SubBatch& b)
 
 }  // namespace
 
+namespace {
+void run_on(Pipeline& g, Job* const* jobs, size_t n);
+}
+
 void run(Job* const* jobs, size_t n)
 {
     if (n == 0) return;
+    const int n_eng = engines();
+    if (n_eng == 1 || n == 1) {
+        run_on(engine_for(jobs[0]->desc.worker_id), jobs, n);
+        return;
+    }
+    // one list per engine (a worker's objects meet one device), each list through its own engine; the
+    // lists run side by side so that the GPUs and their links work at the same time
+    std::vector<std::vector<Job*>> lists((size_t)n_eng);
+    for (size_t i = 0; i < n; ++i) lists[jobs[i]->desc.worker_id % (uint32_t)n_eng].push_back(jobs[i]);
+    std::vector<std::thread> side;
+    int mine = -1;
+    for (int k = 0; k < n_eng; ++k) {
+        if (lists[(size_t)k].empty()) continue;
+        if (mine < 0) { mine = k; continue; }
+        side.emplace_back([&lists, k] { run_on(*g_engines[k], lists[(size_t)k].data(), lists[(size_t)k].size()); });
+    }
+    if (mine >= 0) run_on(*g_engines[mine], lists[(size_t)mine].data(), lists[(size_t)mine].size());
+    for (std::thread& t : side) t.join();
+}
+
+namespace {
+void fail_jobs(Job* const* jobs, size_t n, const char* why)
+{
+    for (size_t i = 0; i < n; ++i) { jobs[i]->failed = true; jobs[i]->err = why; }
+}
+
+void run_on(Pipeline& g, Job* const* jobs, size_t n)
+{
     SubBatch ring[kRunDepthMax];
     const size_t depth = g_run_depth.load(std::memory_order_relaxed);
     const size_t chunk_bytes = g_run_chunk_bytes.load(std::memory_order_relaxed);
@@ -690,14 +924,18 @@ void run(Job* const* jobs, size_t n)
         }
         // A caller never waits for a slot while it holds one (many callers doing so could hold all
         // of them between them): if none is free it completes its own oldest sub-batch first.
-        Slot* slot = live < depth ? try_acquire_slot() : nullptr;
+        Slot* slot = live < depth ? try_acquire_slot(g) : nullptr;
         while (!slot && live) {
             sub_finish(ring[head]);
             head = (head + 1) % depth;
             --live;
-            slot = try_acquire_slot();
+            slot = try_acquire_slot(g);
         }
-        if (!slot) slot = acquire_slot();
+        if (!slot) slot = acquire_slot(g);
+        if (!slot) {
+            fail_jobs(jobs + first, n - first, kNoSlots);
+            break;
+        }
         SubBatch& b = ring[(head + live) % depth];
         b.s = slot;
         b.jobs = jobs + first;
@@ -709,6 +947,7 @@ void run(Job* const* jobs, size_t n)
     }
     for (; live; --live, head = (head + 1) % depth) sub_finish(ring[head]);
 }
+}  // namespace
 
 namespace {
 // Calls inside execute() right now.  While there are no more of them than host
@@ -750,22 +989,32 @@ constexpr size_t kLargeJobBytes = 8u << 20;
 
 void run_large(Job& job)
 {
-    Slot* s = acquire_slot();
+    Slot* s = acquire_slot(engine_for(job.desc.worker_id));
+    if (!s) {
+        job.failed = true;
+        job.err = kNoSlots;
+        return;
+    }
     reset_batch(*s);
     int rc = ensure_slot(*s, 0, 0, 0);
     if (!rc) {
         oval_obj_desc d = job.desc;
         d.body_offset = 0;
         const uint64_t bytes = (uint64_t)d.n_units * kUnit;
+        (void)hipSetDevice(s->pipe->device);
+        (void)oval_internal_wait_timed_out(true);
         if (job.is_fill) rc = oval_fill_batch_host(s->ctx, &d, 1, job.out, bytes);
         else rc = oval_validate_batch_host(s->ctx, &d, 1, job.in, bytes, &job.res, nullptr);
-        if (rc) slot_fail(*s, rc);
+        if (rc) {
+            slot_fail(*s, rc);
+            if (oval_internal_wait_timed_out(true)) s->quarantined = true;   // copies or kernels of it may still be under way
+        }
     }
     if (rc) {
         note_failure(*s);
         job.failed = true;
         job.err = s->err;
-        if (s->ctx) (void)oval_ctx_sync(s->ctx);
+        settle_slot(*s);
     }
     release_slot(s);
 }
@@ -778,6 +1027,7 @@ void execute(Job& job)
         run_large(job);
         return;
     }
+    Pipeline& g = engine_for(job.desc.worker_id);
     const CallerCount here;
     if (here.now <= direct_max()) {
         Job* p = &job;
@@ -817,21 +1067,27 @@ void execute(Job& job)
         Slot* o = g.open.load(std::memory_order_relaxed);
         if (!o) {
             if (!g.free_slots.empty()) {
-                Slot* f = g.free_slots.back();
-                g.free_slots.pop_back();
-                if (!install_open_locked(f)) {
-                    job.failed = true;
-                    job.err = f->err;
+                Slot* f = pop_free_locked(g, true);
+                if (!install_open(lk, g, f)) {
                     g.free_slots.push_back(f);
-                    return;
+                    if (f->failed) {                             // its buffers could not be allocated
+                        job.failed = true;
+                        job.err = f->err;
+                        return;
+                    }
                 }
-                continue;
+                continue;                                        // installed, or somebody else was quicker
+            }
+            if (g.quarantined == kSlots) {
+                job.failed = true;
+                job.err = kNoSlots;
+                return;
             }
         } else if (o != c || !full) {
             continue;                                            // it changed while the lock was taken
         }
         lk.unlock();
-        if (reap_finished_parts()) continue;                     // a landed body was still holding a slot
+        if (reap_finished_parts(g)) continue;                    // a landed body was still holding a slot
         lk.lock();
         if (g.open.load(std::memory_order_relaxed) != o) continue;
         g.slot_waiters++;
@@ -861,11 +1117,28 @@ void execute(Job& job)
         { std::lock_guard<std::mutex> lk(g.mu); }
         g.lane_cv.notify_one();
     }
-    if (const int spin_ns = g_spin_ns.load(std::memory_order_relaxed)) {
-        const uint64_t until = now_ns() + (uint64_t)spin_ns;
-        while (word->load(std::memory_order_acquire) == seq && now_ns() < until) __builtin_ia32_pause();
+    // Polling first, while few enough callers do: a batch is back within tens of microseconds, and a caller
+    // that sees its word change needs neither a sleep nor a wake-up through the kernel.  Then asleep on the
+    // word with its lowest bit set, which tells whoever completes it that a wake-up call is needed.
+    int spin_ns = g_spin_ns.load(std::memory_order_relaxed);
+    if (spin_ns < 0) spin_ns = (int)(2 * g.batch_ns < 200000 ? 2 * g.batch_ns : 200000);
+    if (spin_ns > 0) {
+        int budget = g_spin_budget.load(std::memory_order_relaxed);
+        if (budget < 0) budget = direct_max() / 4;
+        if (g_spinners.fetch_add(1, std::memory_order_relaxed) < budget) {
+            const uint64_t until = now_ns() + (uint64_t)spin_ns;
+            for (uint32_t k = 0; word->load(std::memory_order_acquire) == seq; ++k) {
+                __builtin_ia32_pause();
+                if ((k & 31u) == 31u && now_ns() >= until) break;
+            }
+        }
+        g_spinners.fetch_sub(1, std::memory_order_relaxed);
     }
-    while (word->load(std::memory_order_acquire) == seq) futex_wait(word, seq);
+    if (word->load(std::memory_order_acquire) == seq) {
+        uint32_t expect = seq;
+        if (word->compare_exchange_strong(expect, seq | 1u, std::memory_order_acq_rel, std::memory_order_acquire))
+            while (word->load(std::memory_order_acquire) == (seq | 1u)) futex_wait(word, seq | 1u);
+    }
     wake_children(s, job.is_fill ? s->n_val + idx : idx);        // pass the wake-up on
     if (s->failed) {
         job.failed = true;
@@ -880,9 +1153,9 @@ void execute(Job& job)
 
 void set_lanes(int lanes, int blocking)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    if (lanes >= 1) g.n_lanes = lanes > kMaxLanes ? kMaxLanes : lanes;
-    if (blocking >= 0) g.blocking = blocking ? 1 : 0;
+    std::lock_guard<std::mutex> lk(g_engines_mu);
+    if (lanes >= 1) g_cfg.n_lanes = lanes > kMaxLanes ? kMaxLanes : lanes;
+    if (blocking >= 0) g_cfg.blocking = blocking ? 1 : 0;
 }
 
 void set_run_shape(size_t chunk_bytes, int depth)
@@ -893,7 +1166,22 @@ void set_run_shape(size_t chunk_bytes, int depth)
 
 void set_flag_completion(bool on) { g_flag_completion.store(on, std::memory_order_relaxed); }
 
-void set_caller_spin(int ns) { g_spin_ns.store(ns < 0 ? 0 : ns, std::memory_order_relaxed); }
+void set_caller_spin(int ns) { g_spin_ns.store(ns < -1 ? -1 : ns, std::memory_order_relaxed); }
+
+void set_spin_budget(int callers) { g_spin_budget.store(callers < -1 ? -1 : callers, std::memory_order_relaxed); }
+
+void test_lose_flags(int n) { g_test_lose_flags.store(n < 0 ? 0 : n, std::memory_order_relaxed); }
+
+int quarantined_slots()
+{
+    int q = 0;
+    const int n = engines();
+    for (int k = 0; k < n; ++k) {
+        std::lock_guard<std::mutex> lk(g_engines[k]->mu);
+        q += g_engines[k]->quarantined;
+    }
+    return q;
+}
 
 void set_wake_tree(int fanout, int roots)
 {
@@ -901,80 +1189,125 @@ void set_wake_tree(int fanout, int roots)
     if (roots >= 1) g_wake_roots.store(roots > 64 ? 64 : roots, std::memory_order_relaxed);
 }
 
+namespace {
+
+// g_engines_mu held.
+void start_lanes_locked(Pipeline& g)
+{
+    std::unique_lock<std::mutex> lk(g.mu);
+    ensure_inited_locked(g);
+    g.window_us = g_cfg.window_us;
+    g.n_lanes = g_cfg.n_lanes;
+    g.blocking = g_cfg.blocking;
+    if (g.enabled.load()) return;
+    g.stop = false;
+    g.enabled.store(true, std::memory_order_release);
+    for (int i = 0; i < g.n_lanes; ++i) g.lanes.emplace_back(lane_loop, &g);
+}
+
+// g_engines_mu held.
+void stop_lanes_locked(Pipeline& g)
+{
+    std::unique_lock<std::mutex> lk(g.mu);
+    if (!g.enabled.load()) return;
+    g.enabled.store(false, std::memory_order_release);   // new callers take the direct path
+    g.stop = true;
+    lk.unlock();
+    g.lane_cv.notify_all();
+    for (std::thread& t : g.lanes)
+        if (t.joinable()) t.join();
+    g.lanes.clear();
+    lk.lock();
+    // what the open slot still holds is run here; closing its ticket turns later callers away
+    Slot* s = g.open.load(std::memory_order_relaxed);
+    g.open.store(nullptr, std::memory_order_release);
+    const bool wake = g.slot_waiters > 0;
+    lk.unlock();
+    if (wake) g.slot_cv.notify_all();
+    if (s) {
+        const uint64_t t = s->ticket.fetch_or(kClosed, std::memory_order_acq_rel);
+        if (t_jobs(t) != 0) {
+            process_batch(s, t, false, nullptr);
+            lk.lock();
+            g.batches++;
+            g.jobs += t_jobs(t);
+            lk.unlock();
+        } else {
+            release_slot(s);
+        }
+    }
+}
+
+}  // namespace
+
 void set_batching(bool enable, int window_us, size_t /*max_bytes*/)
 {
-    std::lock_guard<std::mutex> ctl(g.ctl_mu);
-    std::unique_lock<std::mutex> lk(g.mu);
-    ensure_inited_locked();
-    if (window_us >= 0) g.window_us = window_us;
-    if (enable && !g.enabled.load()) {
-        g.stop = false;
-        g.enabled.store(true, std::memory_order_release);
-        for (int i = 0; i < g.n_lanes; ++i) g.lanes.emplace_back(lane_loop);
-    } else if (!enable && g.enabled.load()) {
-        g.enabled.store(false, std::memory_order_release);   // new callers take the direct path
-        g.stop = true;
-        lk.unlock();
-        g.lane_cv.notify_all();
-        for (std::thread& t : g.lanes)
-            if (t.joinable()) t.join();
-        g.lanes.clear();
-        lk.lock();
-        // what the open slot still holds is run here; closing its ticket turns later callers away
-        Slot* s = g.open.load(std::memory_order_relaxed);
-        g.open.store(nullptr, std::memory_order_release);
-        const bool wake = g.slot_waiters > 0;
-        lk.unlock();
-        if (wake) g.slot_cv.notify_all();
-        if (s) {
-            const uint64_t t = s->ticket.fetch_or(kClosed, std::memory_order_acq_rel);
-            if (t_jobs(t) != 0) {
-                process_batch(s, t, false, nullptr);
-                lk.lock();
-                g.batches++;
-                g.jobs += t_jobs(t);
-                lk.unlock();
-            } else {
-                release_slot(s);
+    const int n = engines();
+    std::lock_guard<std::mutex> ctl(g_engines_mu);
+    if (window_us >= 0) g_cfg.window_us = window_us;
+    g_cfg.enabled = enable;
+    for (int k = 0; k < n; ++k) {
+        if (enable) {
+            start_lanes_locked(*g_engines[k]);
+        } else {
+            {
+                std::lock_guard<std::mutex> lk(g_engines[k]->mu);
+                g_engines[k]->window_us = g_cfg.window_us;
             }
+            stop_lanes_locked(*g_engines[k]);
         }
     }
 }
 
 void stats(uint64_t* batches, uint64_t* jobs)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    const uint64_t direct = g_direct_jobs.load(std::memory_order_relaxed);
-    if (batches) *batches = g.batches + direct;
-    if (jobs) *jobs = g.jobs + direct;
+    uint64_t b = g_direct_jobs.load(std::memory_order_relaxed), j = b;
+    const int n = engines();
+    for (int k = 0; k < n; ++k) {
+        std::lock_guard<std::mutex> lk(g_engines[k]->mu);
+        b += g_engines[k]->batches;
+        j += g_engines[k]->jobs;
+    }
+    if (batches) *batches = b;
+    if (jobs) *jobs = j;
 }
 
 void lane_profile(uint64_t out[kProfileWords], bool reset)
 {
-    std::lock_guard<std::mutex> lk(g.mu);
-    for (int i = 0; i < kProfileWords; ++i) {
-        out[i] = g.prof[i];
-        if (reset) g.prof[i] = 0;
+    for (int i = 0; i < kProfileWords; ++i) out[i] = 0;
+    const int n = engines();
+    for (int k = 0; k < n; ++k) {
+        Pipeline& g = *g_engines[k];
+        std::lock_guard<std::mutex> lk(g.mu);
+        for (int i = 0; i < kProfileWords; ++i) {
+            out[i] += g.prof[i];
+            if (reset) g.prof[i] = 0;
+        }
     }
 }
 
 void shutdown()
 {
     set_batching(false, -1, 0);
-    std::lock_guard<std::mutex> ctl(g.ctl_mu);
-    std::unique_lock<std::mutex> lk(g.mu);
-    // every slot must be home before its resources go
-    g.slot_waiters++;
-    while (g.inited && g.free_slots.size() != (size_t)kSlots) {
+    const int n = engines();
+    std::lock_guard<std::mutex> ctl(g_engines_mu);
+    for (int k = 0; k < n; ++k) {
+        Pipeline& g = *g_engines[k];
+        std::unique_lock<std::mutex> lk(g.mu);
+        // every slot must be home (or set aside for good) before its resources go
+        g.slot_waiters++;
+        while (g.inited && g.free_slots.size() + (size_t)g.quarantined != (size_t)kSlots) {
+            lk.unlock();
+            (void)reap_finished_parts(g);                        // generated bodies nobody is reading any more
+            lk.lock();
+            if (!g.inited || g.free_slots.size() + (size_t)g.quarantined == (size_t)kSlots) break;
+            g.slot_cv.wait_for(lk, std::chrono::milliseconds(1));
+        }
+        g.slot_waiters--;
+        for (Slot& s : g.slots) destroy_slot(s);
         lk.unlock();
-        (void)reap_finished_parts();                             // generated bodies nobody is reading any more
-        lk.lock();
-        if (!g.inited || g.free_slots.size() == (size_t)kSlots) break;
-        g.slot_cv.wait_for(lk, std::chrono::milliseconds(1));
+        pool_drop_all(g);
     }
-    g.slot_waiters--;
-    for (Slot& s : g.slots) destroy_slot(s);
-    pool_drop_all();
 }
 
 // ---------------------------------------------------------------------------
@@ -985,9 +1318,13 @@ struct Stream {
     size_t chunk = 0;
 };
 
-Stream* stream_open(size_t chunk_bytes, std::string* err)
+Stream* stream_open(size_t chunk_bytes, uint32_t route, std::string* err)
 {
-    Slot* s = acquire_slot();
+    Slot* s = acquire_slot(engine_for(route));
+    if (!s) {
+        if (err) *err = kNoSlots;
+        return nullptr;
+    }
     reset_batch(*s);
     if (ensure_slot(*s, 2 * chunk_bytes, 0, 2)) {
         note_failure(*s);
@@ -1011,6 +1348,7 @@ int stream_submit(Stream* st, int half, const oval_obj_desc& desc)
     d.body_offset = 0;
     char* dev = (char*)s.up_dev + (size_t)half * st->chunk;
     int rc;
+    (void)hipSetDevice(s.pipe->device);
     if ((rc = oval_copy_h2d(s.ctx, dev, s.up_host + (size_t)half * st->chunk, bytes))) return slot_fail(s, rc);
     if ((rc = oval_layout_reset(s.ctx, s.val_layout, &d, 1))) return slot_fail(s, rc);
     if ((rc = oval_validate(s.ctx, s.val_layout, dev, bytes, s.res_dev + half, nullptr))) return slot_fail(s, rc);
@@ -1023,8 +1361,12 @@ int stream_submit(Stream* st, int half, const oval_obj_desc& desc)
 int stream_wait(Stream* st, int half, oval_obj_result* res)
 {
     Slot& s = *st->s;
-    const hipError_t e = hipEventSynchronize(s.half_ev[half]);
-    if (e != hipSuccess) return hip_fail(s, e, "hipEventSynchronize");
+    (void)oval_internal_wait_timed_out(true);
+    const hipError_t e = oval_internal_wait_event(s.half_ev[half], false);
+    if (e != hipSuccess) {
+        if (oval_internal_wait_timed_out(true)) return slot_timed_out(s, "a chunk of a streamed body");
+        return hip_fail(s, e, "waiting for a chunk");
+    }
     *res = s.res_host[half];
     return OVAL_OK;
 }
@@ -1035,7 +1377,7 @@ void stream_close(Stream* st)
 {
     if (!st) return;
     if (st->s->failed) note_failure(*st->s);
-    (void)oval_ctx_sync(st->s->ctx);
+    settle_slot(*st->s);
     release_slot(st->s);
     delete st;
 }
@@ -1050,33 +1392,20 @@ namespace {
 constexpr size_t kPoolKeepBytes = 2ull << 30;
 constexpr size_t kPoolKeepBuffers = 16;
 
-struct PinnedBuf {
-    uint8_t* p = nullptr;
-    size_t cap = 0;
-};
-
-struct PinnedPool {
-    std::mutex mu;
-    std::vector<PinnedBuf> idle;
-    size_t idle_bytes = 0;
-};
-
-PinnedPool g_pool;
-
 // The smallest idle buffer that fits, or a new one (capacity rounded up so that
 // bodies of similar size share buffers).
-bool pool_take(size_t bytes, PinnedBuf* out, std::string* err)
+bool pool_take(Pipeline& g, size_t bytes, PinnedBuf* out, std::string* err)
 {
     {
-        std::lock_guard<std::mutex> lk(g_pool.mu);
-        size_t best = g_pool.idle.size();
-        for (size_t i = 0; i < g_pool.idle.size(); ++i)
-            if (g_pool.idle[i].cap >= bytes && (best == g_pool.idle.size() || g_pool.idle[i].cap < g_pool.idle[best].cap))
-                best = i;
-        if (best != g_pool.idle.size() && g_pool.idle[best].cap <= 2 * bytes + (1u << 20)) {
-            *out = g_pool.idle[best];
-            g_pool.idle_bytes -= out->cap;
-            g_pool.idle.erase(g_pool.idle.begin() + (long)best);
+        std::lock_guard<std::mutex> lk(g.pool_mu);
+        std::vector<PinnedBuf>& idle = g.pool_idle;
+        size_t best = idle.size();
+        for (size_t i = 0; i < idle.size(); ++i)
+            if (idle[i].cap >= bytes && (best == idle.size() || idle[i].cap < idle[best].cap)) best = i;
+        if (best != idle.size() && idle[best].cap <= 2 * bytes + (1u << 20)) {
+            *out = idle[best];
+            g.pool_idle_bytes -= out->cap;
+            idle.erase(idle.begin() + (long)best);
             return true;
         }
     }
@@ -1094,52 +1423,52 @@ bool pool_take(size_t bytes, PinnedBuf* out, std::string* err)
     return true;
 }
 
-void pool_give(const PinnedBuf& b)
+void pool_give(Pipeline& g, const PinnedBuf& b)
 {
     if (!b.p) return;
     {
-        std::lock_guard<std::mutex> lk(g_pool.mu);
-        if (g_pool.idle.size() < kPoolKeepBuffers && g_pool.idle_bytes + b.cap <= kPoolKeepBytes) {
-            g_pool.idle.push_back(b);
-            g_pool.idle_bytes += b.cap;
+        std::lock_guard<std::mutex> lk(g.pool_mu);
+        if (g.pool_idle.size() < kPoolKeepBuffers && g.pool_idle_bytes + b.cap <= kPoolKeepBytes) {
+            g.pool_idle.push_back(b);
+            g.pool_idle_bytes += b.cap;
             return;
         }
     }
     (void)hipHostFree(b.p);
 }
 
-void pool_drop_all()
+void pool_drop_all(Pipeline& g)
 {
-    std::lock_guard<std::mutex> lk(g_pool.mu);
-    for (const PinnedBuf& b : g_pool.idle) (void)hipHostFree(b.p);
-    g_pool.idle.clear();
-    g_pool.idle_bytes = 0;
+    std::lock_guard<std::mutex> lk(g.pool_mu);
+    for (const PinnedBuf& b : g.pool_idle) (void)hipHostFree(b.p);
+    g.pool_idle.clear();
+    g.pool_idle_bytes = 0;
 }
 
 }  // namespace
 
 struct Parts {
+    Pipeline* pipe = nullptr;             // the engine whose pool and slots the body uses
     Slot* s = nullptr;                    // held until the last slice has landed
     PinnedBuf buf;
     size_t bytes = 0;
     std::vector<hipEvent_t> landed;       // one per staging slice
     std::mutex mu;
     uint32_t landed_upto = 0;             // slices known to have arrived
+    bool timed_out = false;               // a slice did not land within the time limit: buffer and slot are never reused
     std::string err;
 };
 
 namespace {
 
-std::mutex g_parts_mu;
-std::vector<Parts*> g_live_parts;          // bodies that still hold a slot
-
 void parts_forget(Parts* p)
 {
-    std::lock_guard<std::mutex> lk(g_parts_mu);
-    for (size_t i = 0; i < g_live_parts.size(); ++i)
-        if (g_live_parts[i] == p) {
-            g_live_parts[i] = g_live_parts.back();
-            g_live_parts.pop_back();
+    std::lock_guard<std::mutex> lk(p->pipe->parts_mu);
+    std::vector<Parts*>& live = p->pipe->live_parts;
+    for (size_t i = 0; i < live.size(); ++i)
+        if (live[i] == p) {
+            live[i] = live.back();
+            live.pop_back();
             return;
         }
 }
@@ -1149,9 +1478,11 @@ void parts_forget(Parts* p)
 bool parts_advance(Parts* p, uint32_t upto)
 {
     while (p->landed_upto < upto) {                          // slices may land out of order: every one is waited for
-        const hipError_t e = hipEventSynchronize(p->landed[p->landed_upto]);
+        (void)oval_internal_wait_timed_out(true);
+        const hipError_t e = oval_internal_wait_event(p->landed[p->landed_upto], false);
         if (e != hipSuccess) {
-            p->err = std::string("hipEventSynchronize: ") + hipGetErrorString(e);
+            p->err = std::string("waiting for a slice of a generated body: ") + oval_internal_wait_error(e);
+            if (oval_internal_wait_timed_out(true)) p->timed_out = true;
             return false;
         }
         p->landed_upto++;
@@ -1165,19 +1496,19 @@ bool parts_advance(Parts* p, uint32_t upto)
     return true;
 }
 
-bool reap_finished_parts()
+bool reap_finished_parts(Pipeline& g)
 {
     // candidates first, so that no body's lock is taken while the registry's is held
     std::vector<Parts*> live;
     {
-        std::lock_guard<std::mutex> lk(g_parts_mu);
-        live = g_live_parts;
+        std::lock_guard<std::mutex> lk(g.parts_mu);
+        live = g.live_parts;
     }
     bool any = false;
     for (Parts* p : live) {
-        std::unique_lock<std::mutex> reg(g_parts_mu);            // p stays alive while it is registered
+        std::unique_lock<std::mutex> reg(g.parts_mu);            // p stays alive while it is registered
         bool still = false;
-        for (Parts* q : g_live_parts) still |= q == p;
+        for (Parts* q : g.live_parts) still |= q == p;
         if (!still || !p->mu.try_lock()) continue;
         reg.unlock();
         if (p->s && !p->landed.empty() && hipEventQuery(p->landed.back()) == hipSuccess) {
@@ -1197,9 +1528,11 @@ bool reap_finished_parts()
 
 Parts* parts_open(const oval_obj_desc& desc, std::string* err)
 {
+    Pipeline& g = engine_for(desc.worker_id);
     Parts* p = new Parts;
+    p->pipe = &g;
     p->bytes = (size_t)desc.n_units * kUnit;
-    if (!pool_take(p->bytes ? p->bytes : 1, &p->buf, err)) {
+    if (!pool_take(g, p->bytes ? p->bytes : 1, &p->buf, err)) {
         delete p;
         return nullptr;
     }
@@ -1213,13 +1546,20 @@ Parts* parts_open(const oval_obj_desc& desc, std::string* err)
         execute(job);
         if (job.failed) {
             if (err) *err = job.err;
-            pool_give(p->buf);
+            // (a body that failed by a time-out may still be written by the device: its buffer is not reused)
+            if (job.err.find("set aside") == std::string::npos) pool_give(g, p->buf);
             delete p;
             return nullptr;
         }
         return p;
     }
-    Slot* s = acquire_slot();
+    Slot* s = acquire_slot(g);
+    if (!s) {
+        if (err) *err = kNoSlots;
+        pool_give(g, p->buf);
+        delete p;
+        return nullptr;
+    }
     reset_batch(*s);
     int rc = ensure_slot(*s, 0, 0, 0);
     const uint32_t n_slices = oval_internal_host_slices(p->bytes);
@@ -1233,24 +1573,30 @@ Parts* parts_open(const oval_obj_desc& desc, std::string* err)
     if (!rc) {
         oval_obj_desc d = desc;
         d.body_offset = 0;
+        (void)hipSetDevice(g.device);
+        (void)oval_internal_wait_timed_out(true);
         rc = oval_internal_fill_host(s->ctx, &d, 1, p->buf.p, p->bytes, p->landed.data(), n_slices, false);
-        if (rc) slot_fail(*s, rc);
+        if (rc) {
+            slot_fail(*s, rc);
+            if (oval_internal_wait_timed_out(true)) s->quarantined = true;
+        }
     }
     if (rc) {
         note_failure(*s);
         if (err) *err = s->err;
-        if (s->ctx) (void)oval_ctx_sync(s->ctx);
+        settle_slot(*s);                                         // slice copies on all three streams
+        const bool lost = s->quarantined;
         release_slot(s);
         for (hipEvent_t ev : p->landed)
             if (ev) (void)hipEventDestroy(ev);
-        pool_give(p->buf);
+        if (!lost) pool_give(g, p->buf);                         // (a buffer the device may still write is leaked, not pooled)
         delete p;
         return nullptr;
     }
     p->s = s;
     {
-        std::lock_guard<std::mutex> lk(g_parts_mu);
-        g_live_parts.push_back(p);
+        std::lock_guard<std::mutex> lk(g.parts_mu);
+        g.live_parts.push_back(p);
     }
     return p;
 }
@@ -1274,28 +1620,43 @@ const uint8_t* parts_wait(Parts* p, size_t begin, size_t end, std::string* err)
 void parts_close(Parts* p)
 {
     if (!p) return;
+    bool lost = false;
     {
         std::lock_guard<std::mutex> lk(p->mu);
-        // copies still in flight write into the buffer: they must finish before it is reused
-        if (!parts_advance(p, (uint32_t)p->landed.size()) && p->s) {
-            (void)oval_ctx_sync(p->s->ctx);
-            release_slot(p->s);
-            p->s = nullptr;
+        // Copies still in flight write into the buffer: they must finish before it is reused.  The slices
+        // travel on the context's two copy streams, so after a failed wait all three streams are waited
+        // for (with the time limit); a body whose copies cannot be seen to end keeps its buffer and its
+        // slot out of circulation for good.
+        if (!parts_advance(p, (uint32_t)p->landed.size())) {
+            lost = p->timed_out;
+            if (p->s) {
+                if (lost) p->s->quarantined = true;
+                else settle_slot(*p->s);
+                lost |= p->s->quarantined;
+                release_slot(p->s);
+                p->s = nullptr;
+            }
         }
     }
     parts_forget(p);                                         // (a body that never gave its slot back is still listed)
     { std::lock_guard<std::mutex> lk(p->mu); }               // a reaper that found it listed a moment ago is done with it
     for (hipEvent_t ev : p->landed)
         if (ev) (void)hipEventDestroy(ev);
-    pool_give(p->buf);
+    if (!lost) pool_give(*p->pipe, p->buf);
     delete p;
 }
 
 void parts_pool_stats(size_t* buffers, size_t* bytes)
 {
-    std::lock_guard<std::mutex> lk(g_pool.mu);
-    if (buffers) *buffers = g_pool.idle.size();
-    if (bytes) *bytes = g_pool.idle_bytes;
+    size_t nb = 0, by = 0;
+    const int n = engines();
+    for (int k = 0; k < n; ++k) {
+        std::lock_guard<std::mutex> lk(g_engines[k]->pool_mu);
+        nb += g_engines[k]->pool_idle.size();
+        by += g_engines[k]->pool_idle_bytes;
+    }
+    if (buffers) *buffers = nb;
+    if (bytes) *bytes = by;
 }
 
 }  // namespace engine

@@ -25,7 +25,13 @@ struct Job {
     std::string err;
 };
 
-int  init(int device);             // oval_status; idempotent
+// One engine per entry of `devices` (1..16; the same device may appear more than once).  The first call
+// decides; later calls only check that the engines' devices answer.  oval_status.
+int  init_engines(const int* devices, int n);
+// One engine on `device`; with OVAL_HIP_ENGINES=N in the environment N engines on devices device,
+// device + 1, ... modulo the visible GPUs ("all": one per visible GPU).  Idempotent.
+int  init(int device);
+int  engine_count();
 void shutdown();
 std::string last_error();          // text of the most recent engine failure
 
@@ -52,8 +58,18 @@ void set_direct_max(int callers);
 // Whether a small batch on a polling lane signals its end through a flag its kernel writes to pinned
 // host memory (default) or through a stream event.  For benchmarks.
 void set_flag_completion(bool on);
-// A caller polls its wake word this long before it sleeps on it (default 0: sleep at once).
+// A caller of a shared batch polls its wake word this long before it sleeps on it: -1 (default) = about as
+// long as shared batches have lately taken, 0 = sleeps at once, > 0 = that many ns.  At most `callers`
+// callers poll at any moment (set_spin_budget; -1 = default, a quarter of the cores direct launches may
+// use); the rest sleep at once.
 void set_caller_spin(int ns);
+void set_spin_budget(int callers);
+// Test hook: the next `n` small batches that would signal their end through the flag in host memory are
+// launched with a flag word nobody reads and are treated as never finishing, as a hung device would
+// leave them: they end by the device time limit.
+void test_lose_flags(int n);
+// Staging slots set aside for good because their batch did not finish within the device time limit.
+int  quarantined_slots();
 void stats(uint64_t* batches, uint64_t* jobs);
 // Where the lane threads' time went since the last reset, summed over lanes:
 // ns waiting for callers still copying in, ns enqueueing, ns waiting for the
@@ -64,7 +80,7 @@ void lane_profile(uint64_t out[kProfileWords], bool reset);
 // Double-buffered validation of one object's body as it arrives: the caller
 // reads chunk k+1 into one pinned half while chunk k is on the device.
 struct Stream;
-Stream* stream_open(size_t chunk_bytes, std::string* err);
+Stream* stream_open(size_t chunk_bytes, uint32_t route, std::string* err);   // route: the worker ID (picks the engine)
 uint8_t* stream_buffer(Stream* st, int half);              // pinned, chunk_bytes long
 // Validates the first desc.n_units units of half `half` against `desc`
 // (asynchronous); stream_wait returns that half's verdict.

@@ -234,6 +234,20 @@ double go_log2(double x)
 // ---------------------------------------------------------------------------
 int Init(int deviceID) { return engine::init(deviceID); }
 
+int InitEngines(const int* devices, int n) { return engine::init_engines(devices, n); }
+
+int EngineCount() { return engine::engine_count(); }
+
+void SetCallerSpin(int nanos, int maxSpinners)
+{
+    engine::set_caller_spin(nanos);
+    engine::set_spin_budget(maxSpinners);
+}
+
+void TestLoseFlags(int n) { engine::test_lose_flags(n); }
+
+int QuarantinedSlots() { return engine::quarantined_slots(); }
+
 void SetMicroBatching(bool enable, int windowMicros, size_t maxBytes)
 {
     engine::set_batching(enable, windowMicros, maxBytes);
@@ -687,7 +701,7 @@ Error valid_streaming(int64_t workerID, const std::string& bucket16, const objec
                       int64_t nUnits, size_t chunk_bytes)
 {
     std::string eng_err;
-    engine::Stream* st = engine::stream_open(chunk_bytes, &eng_err);
+    engine::Stream* st = engine::stream_open(chunk_bytes, (uint32_t)(uint64_t)workerID, &eng_err);
     if (!st) return Error::New("oval engine failure: " + eng_err);
     struct Pending { bool active = false; uint32_t first = 0, forced = 0; };
     Pending pend[2];
@@ -1037,6 +1051,12 @@ void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes)
 void oval_pattern_set_lanes(int lanes, int blocking_sync) { oval::pattern::SetBatchLanes(lanes, blocking_sync); }
 
 void oval_pattern_set_direct_callers(int callers) { oval::pattern::SetDirectCallers(callers); }
+int oval_pattern_init_engines(const int* devices, int n) { return oval::pattern::InitEngines(devices, n); }
+int oval_pattern_engine_count(void) { return oval::pattern::EngineCount(); }
+void oval_pattern_set_device_timeout(uint64_t ms) { (void)oval_set_device_timeout_ms(ms); }
+void oval_pattern_set_caller_spin(int spin_ns, int max_spinners) { oval::pattern::SetCallerSpin(spin_ns, max_spinners); }
+void oval_pattern_test_lose_flags(int n) { oval::pattern::TestLoseFlags(n); }
+int oval_pattern_quarantined_slots(void) { return oval::pattern::QuarantinedSlots(); }
 void oval_pattern_set_wake_tuning(int fanout, int roots, int spin_ns) { oval::pattern::SetWakeTuning(fanout, roots, spin_ns); }
 
 void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs)

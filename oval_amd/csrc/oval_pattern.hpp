@@ -159,7 +159,11 @@ std::string dump(const std::string& data);
 std::string hexDump(const uint8_t* data, size_t n);
 
 // Engine control (no counterpart in the reference).
-int  Init(int deviceID);            // oval_status
+int  Init(int deviceID);            // oval_status; one engine on that GPU (OVAL_HIP_ENGINES=N or "all" in the environment: more)
+// One engine per entry of `devices` (a GPU may be named more than once); calls are routed by worker ID,
+// so a worker's objects always meet the same GPU.  The first Init / InitEngines call decides.
+int  InitEngines(const int* devices, int n);
+int  EngineCount();
 void Shutdown();
 void SetClock(int64_t unixMicro);   // >= 0 pins time.Now().UnixMicro(); < 0 = wall clock
 void Seed(uint64_t seed);           // source of rand.Float64() in DecideSize
@@ -179,6 +183,15 @@ void SetBatchLanes(int lanes, int blockingSync);
 // more; defaults 1 and 4) and how long a caller polls before it sleeps (default 0).  Values < 0 keep
 // the setting.  For benchmarks.
 void SetWakeTuning(int fanout, int roots, int spinNanos);
+// How long a caller of a shared batch polls for its outcome before it sleeps (-1 = about as long as
+// shared batches have lately taken: the default; 0 = never) and how many callers may poll at once
+// (-1 = a quarter of the cores that direct launches may use).
+void SetCallerSpin(int nanos, int maxSpinners);
+// Test hook: the next n small batches are launched so that their completion is never seen (as on a
+// device that hangs); they end by the device time limit (oval_set_device_timeout_ms) and cost their
+// staging slots, which QuarantinedSlots counts.
+void TestLoseFlags(int n);
+int  QuarantinedSlots();
 // How GenerateBatch / ValidBatch cut a large batch into sub-batches that travel through the device one
 // behind the other: at most `chunkBytes` each (0 keeps the setting; default 16 MiB), `depth` in flight
 // (0 keeps it; default 3).  For benchmarks.

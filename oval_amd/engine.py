@@ -225,6 +225,12 @@ class Comm:
         self._h = C.c_void_p()
         check(_lib.lib().oval_comm_create(ctx.handle, n_ranks, rank, uid, C.byref(self._h)))
 
+    def info(self):
+        """(ranks in the communicator, this rank), as RCCL reports them."""
+        n, me = C.c_int(), C.c_int()
+        check(_lib.lib().oval_comm_info(self._h, C.byref(n), C.byref(me)))
+        return n.value, me.value
+
     def all_reduce_counters(self, counters) -> None:
         """counters: int64 CUDA tensor, summed over all ranks in place on the context's stream."""
         check(_lib.lib().oval_allreduce_counters(self.ctx.handle, self._h, counters.data_ptr(), counters.numel()))

@@ -39,6 +39,38 @@ def init(device: int = 0) -> None:
     _lib.check(_lib.lib().oval_pattern_init(device))
 
 
+def init_engines(devices) -> None:
+    """One engine per entry of `devices` (a GPU may be named more than once);
+    calls are routed by worker ID modulo the engine count."""
+    arr = (C.c_int * len(devices))(*devices)
+    _lib.check(_lib.lib().oval_pattern_init_engines(arr, len(devices)))
+
+
+def engine_count() -> int:
+    return _lib.lib().oval_pattern_engine_count()
+
+
+def set_device_timeout(ms: int) -> None:
+    """How long a call waits for the device before it fails (default 30000 ms; 0 = no limit)."""
+    _lib.lib().oval_pattern_set_device_timeout(ms)
+
+
+def set_caller_spin(spin_ns: int = -1, max_spinners: int = -1) -> None:
+    _lib.lib().oval_pattern_set_caller_spin(spin_ns, max_spinners)
+
+
+def test_lose_flags(n: int) -> None:
+    """Test hook: the next n small launches never report their end (a hung device)."""
+    _lib.lib().oval_pattern_test_lose_flags(n)
+
+
+test_lose_flags.__test__ = False          # not a pytest test
+
+
+def quarantined_slots() -> int:
+    return _lib.lib().oval_pattern_quarantined_slots()
+
+
 def shutdown() -> None:
     _lib.lib().oval_pattern_shutdown()
 
@@ -87,8 +119,17 @@ class GeneratedParts:
     def __len__(self) -> int:
         return _lib.lib().oval_parts_count(self._h) if self._h else 0
 
+    def _handle(self):
+        if self._h is None:
+            raise OvalError("this generated body has been closed: its buffer is back in the library's pool")
+        return self._h
+
     def part(self, i: int) -> np.ndarray:
-        """A view (not a copy) of part i; valid until release(i) / close()."""
+        """A view (not a copy) of part i, straight into the library's pooled pinned
+        buffer: valid until release(i) / close() and not kept alive by numpy.  The
+        buffer is recycled as soon as the last part has been released, so take a
+        copy (`.copy()`) of anything that must outlive its release."""
+        self._handle()
         data, n = C.c_void_p(), C.c_size_t()
         err = C.create_string_buffer(_ERR_CAP)
         rc = _lib.lib().oval_parts_get(self._h, i, C.byref(data), C.byref(n), err, _ERR_CAP)
@@ -98,7 +139,7 @@ class GeneratedParts:
         return np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint8)), shape=(n.value,))
 
     def release(self, i: int) -> None:
-        _lib.check(_lib.lib().oval_parts_release(self._h, i))
+        _lib.check(_lib.lib().oval_parts_release(self._handle(), i))
 
     def close(self) -> None:
         if self._h:

@@ -130,16 +130,28 @@ def test_bench_shards_one_key_space_by_worker_range():
     import bench
 
     world = 8
-    shards = [bench.build_batch("cfg5", r, world, "workers", 2480, 1)[0] for r in range(world)]
+    shards = [bench.build_batch("cfg5", r, world, "workers", 2500, 1)[0] for r in range(world)]
     keys = np.concatenate([s["key"] for s in shards])
-    assert len(np.unique(keys, axis=0)) == len(keys) == 8 * 2480 - (8 * 2480) % 248
+    assert len(np.unique(keys, axis=0)) == len(keys) == 8 * 2500
     texts = [bytes(k).decode() for k in keys]
     assert all(t.startswith("ov00") for t in texts)                      # process ID 0 everywhere
     workers = sorted({int(t[4:6], 16) for t in texts})
-    assert workers == list(range(248))                                   # 31 workers per rank, 248 < 256
+    assert workers == list(range(200))                                   # 25 workers per rank, 200 < 256
     for r, s in enumerate(shards):
         w = {int(bytes(k).decode()[4:6], 16) for k in s["key"]}
-        assert w == set(range(31 * r, 31 * r + 31))
+        assert w == set(range(25 * r, 25 * r + 25))
+    # weak scaling means the same work per GPU at every N: same objects, workers and (per worker
+    # stream) sizes on rank 0 whether the job has 1, 2, 4 or 8 ranks
+    for name in ("cfg2", "cfg3", "cfg5"):
+        n_obj = 5000 if name != "cfg3" else 0
+        ref = bench.build_batch(name, 0, 1, "workers", n_obj, 1)[0]
+        for w in (2, 4, 8):
+            d = bench.build_batch(name, 0, w, "workers", n_obj, 1)[0]
+            assert len(d) == len(ref) and np.array_equal(d["n_units"], ref["n_units"])
+            assert np.array_equal(d["key"], ref["key"])
+    full = bench.WORKLOADS
+    assert full["cfg2"][0] % full["cfg2"][1] == 0 and full["cfg5"][0] % full["cfg5"][1] == 0
+    assert 8 * full["cfg5"][0] == 10_000_000 and 8 * full["cfg5"][1] < 256
     # the same objects whatever the world size: a worker's stream does not depend on the cut
     one = bench.build_batch("cfg5", 0, 1, "workers", 0, 1)[1]
     assert "one key space" in one

@@ -83,3 +83,37 @@ def test_two_ranks_sum_to_the_whole(tmp_path):
     keys = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])
     whole = synthetic_batch(WorkerSpace(**SPACE), range(SPACE["num_worker"]), "test-bucket", 4096, 16384, 7, T0)
     assert (keys == whole["key"]).all() and len(np.unique(keys, axis=0)) == SPACE["num_obj"]
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE around it: the parent starts two
+    fresh rank processes before anything touches a GPU, relays rank 0's one line
+    and fails when a rank fails.  --rehearse-launch keeps the engine out of it (no
+    GPU here): rendezvous, the cut of the key space and one sum over ranks."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--rehearse-launch", "--objects", "5000"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] is None and "rehearsal" in d
+    assert d["config"]["ranks_seen"] == 2 and d["config"]["launcher"] == "self"
+    assert d["config"]["objects_all"] == 2 * d["config"]["objects_per_gpu"] == 10000
+    # a rank that fails (no GPU in this container: the engine refuses to start) fails the whole job
+    if not _has_gpu():
+        p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--objects", "100"],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=240)
+        assert p.returncode != 0 and p.stdout.strip() == ""
+        assert "needs a GPU" in p.stderr and "a rank failed" in p.stderr
+
+
+def _has_gpu():
+    import torch
+
+    return torch.cuda.is_available()

@@ -39,20 +39,40 @@ def test_single_rank_line():
     # HBM traffic of the dominant kernel, measured by a child PMC run of the same command: within a few
     # per cent of the algorithmic bytes (descriptor and table reads on top of the bodies)
     r = d["roofline"]
+    rf, rv = d["roofline_fill"], d["roofline_validate"]
+    assert rf["kernel"].startswith("fill_kernel") and rv["kernel"].startswith("validate_kernel")
+    assert r["kernel"] in (rf["kernel"], rv["kernel"]) and r["frac"] == min(rf["frac"], rv["frac"])
+    for k in (rf, rv):
+        assert k["launches_per_step"] >= 1 and k["avg_launch_ms"] > 0 and 0 < k["frac"] < 1
+        assert abs(k["avg_launch_ms"] * k["launches_per_step"] - k["pass_ms"]) < 0.01 * k["pass_ms"] + 1e-3
     if r["traffic_source"].startswith("measured in this run"):
-        assert 1.0 <= r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.15
+        # both kernels, two PMC passes: the fill writes its bytes once and reads tables on top, the
+        # validate reads its bytes once (plus descriptors) and writes next to nothing
+        assert 1.0 <= rv["traffic"] / rv["algorithmic_bytes_per_launch"] < 1.15
+        assert 0.99 <= rf["traffic_write"] / rf["algorithmic_bytes_per_launch"] < 1.02
+        assert rf["traffic_read"] < 0.25 * rf["algorithmic_bytes_per_launch"]
+        assert r["traffic"] in (rf["traffic"], rv["traffic"])
     else:
         # no profiler on this box (or this test itself runs under one): the line must say why, and must
-        # not pass a number off as measured (a non-default shape has no stored PMC pass to fall back to)
+        # not pass a number off as measured
         assert r["traffic"] is None and len(r["traffic_source"]) > 8, r["traffic_source"]
+    # the other two single-GPU configurations under the same clock
+    a = d["also"]
+    assert set(a) == {"cfg3", "cfg4"}
+    assert a["cfg3"]["bytes_per_gpu"] == 64 * (256 << 20) and a["cfg3"]["value"] > 1000 and 0 < a["cfg3"]["frac"] < 1
+    assert a["cfg3"]["fill_ms"] > 0 and a["cfg3"]["validate_ms"] > 0
+    assert a["cfg4"]["counters_equal_plan"] is True and a["cfg4"]["counters"][3] > 0 and a["cfg4"]["value"] > 100
+    assert d["config"]["ranks_seen"] == 1 and d["config"]["collective"] in ("capi", "torch")
 
 
 def test_two_rank_rehearsal_sums_units_over_ranks():
-    d = _one_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                   "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2",
-                   "--backend", "gloo", "--objects", "40000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"])
+    # no launcher: bench.py starts its own two rank processes
+    d = _one_line([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--objects", "40000",
+                   "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-also"])
     assert d["roofline"]["traffic"] is None                 # PMC passes are taken at N = 1 only
     assert REQUIRED <= set(d) and d["n_gpus"] == 2 and "cpu_baseline" not in d
+    assert d["config"]["launcher"] == "self" and d["config"]["ranks_seen"] == 2
+    assert d["config"]["collective"] == "torch"             # gloo: two ranks on one GPU cannot run RCCL
     # whole-job value: both ranks' units over the slowest rank's time
     per_gpu = d["config"]["units_per_gpu"]
     assert abs(d["value"] - 512.0 * 2 * per_gpu / (d["ms_per_step"] / 1e3) / 1e9) / d["value"] < 0.05
@@ -63,13 +83,15 @@ def test_two_rank_rehearsal_with_damage_counters_equal_the_oracle(sharding):
     """cfg5's shape in small: two ranks, each damages its own shard (seeded per
     rank), one all-reduce of the 12 counters; rank 0 recomputes the WHOLE batch
     with the CPU oracle and requires every counter to match."""
-    port = "29543" if sharding == "workers" else "29545"
-    d = _one_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                   "--master-addr", "127.0.0.1", "--master-port", port, "bench.py", "--gpus", "2",
-                   "--backend", "gloo", "--objects", "30000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
-                   "--workload", "cfg5", "--sizes", "4096-262144", "--corrupt", "1e-4", "--verify-oracle",
-                   "--sharding", sharding, "--global-table"])
+    cmd = [sys.executable, "bench.py", "--gpus", "2"]        # workers: self-launched; process: under torchrun
+    if sharding == "process":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29545", "bench.py", "--gpus", "2"]
+    d = _one_line(cmd + ["--backend", "gloo", "--objects", "30000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+                         "--workload", "cfg5", "--sizes", "4096-262144", "--corrupt", "1e-4", "--verify-oracle",
+                         "--sharding", sharding, "--global-table"])
     assert d["counters_equal_oracle"] is True
+    assert d["config"]["launcher"] == ("self" if sharding == "workers" else "external")
     # the optional second form of the exchange: every rank ends up with the first bad unit of every object
     # of the job (minimum over ranks of tables that each hold one rank's share)
     assert d["global_table_equals_oracle"] is True
@@ -79,6 +101,14 @@ def test_two_rank_rehearsal_with_damage_counters_equal_the_oracle(sharding):
     assert c[0] == 2 * d["config"]["objects_per_gpu"] and c[1] > 0 and c[3] >= c[1] and c[9] >= c[3]
     if sharding == "workers":
         assert "one key space (process ID 0)" in d["config"]["sharding"]
+
+
+def test_capi_is_the_default_collective_with_one_rank():
+    """Under the RCCL backend the counter sum runs through the library's own entry point
+    (oval_allreduce_counters -> ncclAllReduce); the rank count in the line is the communicator's."""
+    d = _one_line([sys.executable, "bench.py", "--objects", "20000", "--steps", "2", "--warmup", "1",
+                   "--cpu-seconds", "0", "--no-traffic", "--no-also"])
+    assert d["config"]["collective"] == "capi" and d["config"]["ranks_seen"] == 1, d["config"]
 
 
 def test_capi_collective_refuses_more_ranks_than_gpus():

@@ -107,6 +107,13 @@ int main(int argc, char** argv)
     if (pattern::Init(0) != 0) { std::fprintf(stderr, "init failed: %s\n", pattern::LastEngineError().c_str()); return 1; }
     pattern::Seed(1);
     pattern::SetWakeTuning(fanout, roots, spin);
+    if (const char* e = std::getenv("COMPAT_SPIN")) {          // "<ns>,<callers that may poll at once>"; -1 = the library's default
+        int ns = -1, budget = -1;
+        std::sscanf(e, "%d,%d", &ns, &budget);
+        pattern::SetCallerSpin(ns, budget);
+        std::printf("caller spin %d ns, at most %d callers polling (-1 = default)\n", ns, budget);
+    }
+    std::printf("engines: %d\n", pattern::EngineCount());
     if (argc > 10) {
         pattern::SetDirectCallers(atoi(argv[10]));
         std::printf("calls launch on their own while at most %d are under way\n", atoi(argv[10]));
