@@ -150,8 +150,8 @@ void oval_pattern_set_wake_tuning(int fanout, int roots, int spin_ns);
  * the micro-batcher). */
 void oval_pattern_set_direct_callers(int callers);
 /* How long a caller of a shared launch polls for its outcome before it sleeps
- * (-1, the default: about as long as shared launches have lately taken; 0:
- * never) and how many callers may poll at the same time (-1: a quarter of the
+ * (0, the default: never; -1: about as long as shared launches have lately
+ * taken) and how many callers may poll at the same time (-1: a quarter of the
  * cores that calls launching on their own may use). */
 void oval_pattern_set_caller_spin(int spin_ns, int max_spinners);
 /* Test hook: the next n small launches never report their end, as on a device

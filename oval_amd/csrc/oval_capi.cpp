@@ -1053,6 +1053,7 @@ int oval_validate_noalloc(oval_ctx* ctx, const oval_obj_desc* descs_dev, uint64_
     if (body_bytes < span_bytes)
         return fail(OVAL_E_RANGE, "body holds %llu bytes but the span is %llu", (unsigned long long)body_bytes,
                     (unsigned long long)span_bytes);
+    HIP_TRY(hipSetDevice(ctx->device));                          // (the calling thread may last have used another GPU)
     HIP_TRY(oval::launch_validate_noalloc(ctx->stream, ctx->device, cfg_of(ctx), descs_dev, (uint32_t)n_obj,
                                           (uint32_t)(span_bytes / OVAL_UNIT_SIZE), body_dev, results_dev,
                                           (unsigned long long*)counters_dev));

@@ -102,9 +102,12 @@ void futex_wake(std::atomic<uint32_t>* a, int n)
 // batch of 100 jobs), during which that lane submits nothing.
 constexpr int kWakeFanout = 4, kWakeRoots = 1;
 std::atomic<int> g_wake_fanout{kWakeFanout}, g_wake_roots{kWakeRoots};   // set_wake_tree(): benchmarks only
-// How long a caller polls its wake word before it sleeps on it: -1 = as long as batches have lately taken
-// on the device (while fewer callers than g_spin_budget are polling), 0 = never, > 0 = that many ns.
-std::atomic<int> g_spin_ns{-1};
+// How long a caller polls its wake word before it sleeps on it: 0 = never (the default: on a 16-core host
+// polling lost at every thread count from 32 to 255, 10-25 % with the adaptive setting and four pollers,
+// because the cores a poller holds are the ones the other callers need to copy their bodies), -1 = as
+// long as batches have lately taken on the device (while fewer callers than g_spin_budget are polling),
+// > 0 = that many ns.
+std::atomic<int> g_spin_ns{0};
 std::atomic<int> g_spin_budget{-1};        // callers that may poll at once; -1: a quarter of the host's cores
 std::atomic<int> g_spinners{0};
 std::atomic<int> g_test_lose_flags{0};     // test hook: that many coming flag batches never see their flag

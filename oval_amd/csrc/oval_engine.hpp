@@ -58,8 +58,8 @@ void set_direct_max(int callers);
 // Whether a small batch on a polling lane signals its end through a flag its kernel writes to pinned
 // host memory (default) or through a stream event.  For benchmarks.
 void set_flag_completion(bool on);
-// A caller of a shared batch polls its wake word this long before it sleeps on it: -1 (default) = about as
-// long as shared batches have lately taken, 0 = sleeps at once, > 0 = that many ns.  At most `callers`
+// A caller of a shared batch polls its wake word this long before it sleeps on it: 0 (default) = sleeps at
+// once, -1 = about as long as shared batches have lately taken, > 0 = that many ns.  At most `callers`
 // callers poll at any moment (set_spin_budget; -1 = default, a quarter of the cores direct launches may
 // use); the rest sleep at once.
 void set_caller_spin(int ns);

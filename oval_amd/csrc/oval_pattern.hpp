@@ -183,8 +183,8 @@ void SetBatchLanes(int lanes, int blockingSync);
 // more; defaults 1 and 4) and how long a caller polls before it sleeps (default 0).  Values < 0 keep
 // the setting.  For benchmarks.
 void SetWakeTuning(int fanout, int roots, int spinNanos);
-// How long a caller of a shared batch polls for its outcome before it sleeps (-1 = about as long as
-// shared batches have lately taken: the default; 0 = never) and how many callers may poll at once
+// How long a caller of a shared batch polls for its outcome before it sleeps (0 = never, the default; -1 = about as long as
+// shared batches have lately taken) and how many callers may poll at once
 // (-1 = a quarter of the cores that direct launches may use).
 void SetCallerSpin(int nanos, int maxSpinners);
 // Test hook: the next n small batches are launched so that their completion is never seen (as on a

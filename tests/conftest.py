@@ -46,4 +46,5 @@ def golden():
     return {
         "readme": json.load(open(os.path.join(d, "readme_unit.json"))),
         "pattern_test": json.load(open(os.path.join(d, "pattern_test.json"))),
+        "short_read": json.load(open(os.path.join(d, "short_read.json"))),
     }

@@ -9,6 +9,12 @@ Sources (data only, no reference source text is copied):
     the annotated hex dump of one complete 256-byte unit.
   * internal/pattern/pattern_test.go:30-255 — the byte values and size ranges
     its assertions state, typed in below as numbers/strings.
+  * short_read.json — the message of Valid for a body that ends early
+    (pattern.go:126), assembled from what the reference itself pins: the layout
+    of a full hex.Dump line and the three annotation rows as README.md:100-108
+    prints them, and dump's rule for text that runs out before the annotations
+    do (pattern.go:195-199).  The one thing no file of the reference shows, a
+    hex.Dump line of fewer than 16 bytes, is kept apart as `unpinned_tail`.
 """
 import json
 import os
@@ -83,7 +89,64 @@ def pattern_test_fixture():
     }
 
 
+def short_read_fixture():
+    rd = readme_fixture()
+    unit1 = bytes.fromhex(rd["unit_hex"])
+    dump_lines = [ln for ln in rd["message"].split("\n") if re.match(r"^[0-9a-f]{8}  ", ln)]
+    notes = [ln for ln in rd["message"].split("\n") if ln.startswith("   ")]
+    assert len(dump_lines) == 16 and len(notes) == 6
+    ann = ["\n".join(notes[0:1]) + "\n", "\n".join(notes[1:3]) + "\n", "\n".join(notes[3:6]) + "\n"]
+
+    def full_line(off, b):
+        # a complete line as README.md:100-121 prints sixteen of them
+        assert len(b) == 16
+        hx = " ".join("%02x" % x for x in b[:8]) + "  " + " ".join("%02x" % x for x in b[8:])
+        tx = "".join(chr(x) if 0x20 <= x <= 0x7e else "." for x in b)
+        return "%08x  %s  |%s|" % (off, hx, tx)
+
+    for i, ln in enumerate(dump_lines):                       # the formatter is held to all sixteen README lines
+        assert full_line(16 * i, unit1[16 * i:16 * i + 16]) == ln, (i, ln)
+
+    def unit(k):                                              # the README unit at another place in its object
+        u = bytearray(unit1)
+        u[32:36] = (k * 256).to_bytes(4, "little")
+        return bytes(u)
+
+    def dump_of_full_lines(data):                             # pattern.go:182-206 over whole lines only
+        text = [full_line(o, data[o:o + 16]) + "\n" for o in range(0, len(data), 16)]
+        out = ""
+        for a in ann:
+            if not text:                                      # pattern.go:195-199: nothing left, the annotation still goes out
+                return out + a
+            out += text.pop(0) + a
+        return out + "".join(text)
+
+    cases = []
+    for n in (0, 16, 32, 176):
+        body = unit(0) + unit(1) + unit(2)[:n]
+        msg = "could not read some data. (expected: 256byte, actual: %dbyte)\n" % n
+        msg += dump_of_full_lines(unit(2)[:n]) if n else ""
+        cases.append({"body_hex": body.hex(), "size": 768, "read": n, "message": msg, "unpinned_tail": ""})
+    # 700 bytes: 188 of unit 2 arrive = eleven whole lines and one of twelve bytes.  The whole lines and
+    # annotations above are pinned; the twelve-byte line follows encoding/hex.Dump as Go documents it (hex
+    # columns padded with spaces to full width, then the characters that exist) and is NOT pinned by any
+    # file of the reference.
+    n = 188
+    body = unit(0) + unit(1) + unit(2)[:n]
+    pinned = "could not read some data. (expected: 256byte, actual: %dbyte)\n" % n + dump_of_full_lines(unit(2)[:176])
+    last = unit(2)[176:188]
+    hx = " ".join("%02x" % x for x in last[:8]) + "  " + " ".join("%02x" % x for x in last[8:])
+    tail = "%08x  %s" % (176, hx) + " " * (3 * 4) + "  |" + "".join(chr(x) if 0x20 <= x <= 0x7e else "." for x in last) + "|\n"
+    cases.append({"body_hex": body.hex(), "size": 768, "read": n, "message": pinned, "unpinned_tail": tail})
+    return {
+        "source": "README.md:100-121 (line layout, annotation rows) + internal/pattern/pattern.go:126,182-206",
+        "state": {"bucket": "test-bucket", "key": "ov00020000e2", "write_count": 1, "worker_id": 0x561B},
+        "cases": cases,
+    }
+
+
 if __name__ == "__main__":
     json.dump(readme_fixture(), open(os.path.join(HERE, "readme_unit.json"), "w"), indent=1)
     json.dump(pattern_test_fixture(), open(os.path.join(HERE, "pattern_test.json"), "w"), indent=1)
-    print("wrote readme_unit.json, pattern_test.json")
+    json.dump(short_read_fixture(), open(os.path.join(HERE, "short_read.json"), "w"), indent=1)
+    print("wrote readme_unit.json, pattern_test.json, short_read.json")

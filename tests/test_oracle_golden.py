@@ -191,6 +191,25 @@ def test_hex_dump_matches_the_go_documentation_example(oracle):
     assert oracle.hex_dump(b"Go is an open source programming language.") == want
 
 
+def test_short_read_messages_assembled_from_the_readme_layout(oracle, golden):
+    """Valid over a body that ends early (pattern.go:124-127).  The expected texts
+    are put together by tests/golden/make_golden.py from what the reference pins:
+    whole hex.Dump lines and annotation rows as README.md:100-121 prints them, and
+    dump's rule for text that runs out early (pattern.go:195-199; 0, 16 and 32
+    bytes read).  For the 700-byte body (188 bytes of the third unit) everything up
+    to the last whole line is pinned that way; the final twelve-byte line is the
+    part no file of the reference shows (`unpinned_tail`)."""
+    g = golden["short_read"]
+    st = g["state"]
+    for c in g["cases"]:
+        body = bytes.fromhex(c["body_hex"])
+        kind, unit, text = oracle.valid(st["worker_id"], st["bucket"], st["key"], c["size"], st["write_count"], body)
+        assert (kind, unit) == (2, 2), c["read"]
+        assert text.startswith(c["message"]), c["read"]
+        assert text == c["message"] + c["unpinned_tail"], c["read"]
+    assert [c["read"] for c in g["cases"]] == [0, 16, 32, 176, 188] and len(bytes.fromhex(g["cases"][-1]["body_hex"])) == 700
+
+
 def test_dump_annotations(oracle):
     assert oracle.dump("") == ""
     text = oracle.hex_dump(bytes(256))

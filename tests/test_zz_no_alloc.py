@@ -1,8 +1,10 @@
 """oval_validate_noalloc (the entry point that allocates nothing) against
-oval_layout_create + oval_validate, through the C ABI: same result words and
-counters, bit for bit, on two calls in a row of which the second is smaller
-(the static scratch keeps the first call's chunk table), then on a body with
-gaps, and the size limit."""
+oval_layout_create + oval_validate AND against the CPU oracle, through the C
+ABI: same result words and counters, bit for bit, on two calls in a row of which
+the second is smaller (the static scratch keeps the first call's chunk table),
+then on a body with gaps; the size limit; and a table that breaks the ordering
+rule, which may give meaningless results but must not write outside the result
+and counter arrays it was given."""
 import ctypes as C
 
 import numpy as np
@@ -53,7 +55,7 @@ def _damaged_batch(torch, engine, ctx, n_obj, seed, gap_bytes=0, lo=4096, hi=163
     return descs, body
 
 
-def test_noalloc_matches_layout_validate_twice_second_smaller():
+def test_noalloc_matches_layout_validate_twice_second_smaller(oracle):
     import torch
 
     from oval_amd import _lib, engine
@@ -69,6 +71,58 @@ def test_noalloc_matches_layout_validate_twice_second_smaller():
                 bad = np.flatnonzero(a[f] != b[f])
                 assert bad.size == 0, (n_obj, f, bad[:5], a[f][bad[:5]], b[f][bad[:5]])
             assert np.array_equal(ca, cb), (n_obj, ca, cb)
+            # and both equal the oracle's verdicts over the same damaged bytes
+            eres, ecnt = oracle.validate_batch(descs.view(oracle.DESC_DTYPE), body.cpu().numpy())
+            for f in eres.dtype.names:
+                bad = np.flatnonzero(b[f] != eres[f])
+                assert bad.size == 0, (n_obj, f, bad[:5], b[f][bad[:5]], eres[f][bad[:5]])
+            assert np.array_equal(cb.astype(np.uint64), ecnt), (n_obj, cb, ecnt)
+    finally:
+        ctx.close()
+
+
+def test_noalloc_table_that_breaks_the_rules_stays_inside_its_arrays():
+    """The descriptor table of the no-alloc entry point never passes through the
+    host, so its ordering cannot be checked: bodies out of order, overlapping,
+    beyond the span or absurdly long give results that mean nothing, but every
+    write must land in results[0, n_obj) or counters[0, 12) (guard words on both
+    sides stay as they were) and the call must end."""
+    import torch
+
+    from oval_amd import _lib, engine
+    from oval_amd._lib import check
+    from oval_amd.batch import span_bytes
+
+    lib = _lib.lib()
+    ctx = engine.Context.on_torch_stream(0)
+    try:
+        descs, body = _damaged_batch(torch, engine, ctx, 400, 31)
+        span = span_bytes(descs)
+        rng = np.random.default_rng(7)
+        broken = descs.copy()
+        rng.shuffle(broken)                                     # not ascending any more
+        broken["body_offset"][5] = broken["body_offset"][6]     # two objects on the same bytes
+        broken["body_offset"][9] = span + (1 << 20)             # beyond the span
+        broken["n_units"][11] = 0xFFFFFF00                      # far longer than the body
+        broken["body_offset"][13] = (1 << 40) - 256             # unit index near the top of its 32 bits
+        n, guard = len(broken), 64
+        res = torch.full((n + 2 * guard, 4), 0x5A5A5A5A, dtype=torch.int32, device="cuda:0")
+        cnt = torch.full((engine.NUM_COUNTERS + 2 * guard,), 0x1234567, dtype=torch.int64, device="cuda:0")
+        cnt[guard:guard + engine.NUM_COUNTERS] = 0
+        descs_dev = torch.from_numpy(broken.view(np.uint8).reshape(-1).copy()).to("cuda:0")
+        torch.cuda.synchronize()
+        check(lib.oval_validate_noalloc(ctx.handle, descs_dev.data_ptr(), n, span, body.data_ptr(), body.numel(),
+                                        res[guard:].data_ptr(), cnt[guard:].data_ptr()))
+        ctx.sync()
+        r, c = res.cpu().numpy(), cnt.cpu().numpy()
+        assert (r[:guard] == 0x5A5A5A5A).all() and (r[guard + n:] == 0x5A5A5A5A).all()
+        assert (c[:guard] == 0x1234567).all() and (c[guard + engine.NUM_COUNTERS:] == 0x1234567).all()
+        assert c[guard + engine_cnt("OBJECTS_CHECKED")] == n
+        # the scratch is whole afterwards: a well-formed call right behind it is exact again
+        a, ca, b, cb = _both(torch, engine, lib, ctx, descs, body)
+        for f in a.dtype.names:
+            assert np.array_equal(a[f], b[f]), f
+        assert np.array_equal(ca, cb)
     finally:
         ctx.close()
 
