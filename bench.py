@@ -195,10 +195,14 @@ def measure_traffic(argv_tail, launches):
     this box: two child runs of this same bench under `rocprofv3 --pmc`, one
     counter each (FETCH_SIZE and WRITE_SIZE do not fit one pass; the profiler
     cannot be attached from inside).  Counter units are KiB; FETCH_SIZE tallies the
-    128-byte requests of a wide streaming read at 64 bytes each on gfx950, so read
-    bytes = 2 x FETCH_SIZE x 1024 (the fill kernel's scalar table reads are
-    corrected alike: uncalibrated, an upper bound).  `launches` = {kernel name
-    prefix: launches per pass}.  Returns ({prefix: {"read": B, "write": B}} per
+    128-byte requests of a wide streaming read (16 bytes per lane) at 64 bytes
+    each on gfx950, so read bytes = 2 x FETCH_SIZE x 1024 for the validate kernel
+    and the table pre-pass.  The fill kernel reads nothing but 64-byte records with
+    scalar loads, which the counter tallies at full size (calibrated with
+    tools/scalar_fetch_probe.hip: 1.000 x a table read once that way, 0.500 x with
+    wide loads), so its read bytes = FETCH_SIZE x 1024.  The validate kernel's own
+    descriptor reads (scalar, about 1 % of its bytes) are doubled with the rest: an
+    upper bound.  `launches` = {kernel name prefix: launches per pass}.  Returns ({prefix: {"read": B, "write": B}} per
     launch, how) or (None, why not)."""
     import csv
     import glob
@@ -230,7 +234,8 @@ def measure_traffic(argv_tail, launches):
                         continue
                     for prefix in launches:
                         if ("oval::" + prefix) in r["Kernel_Name"]:
-                            got[prefix][key] = got[prefix].get(key, 0.0) + float(r["Counter_Value"]) * 1024.0 * scale
+                            k_scale = 1.0 if (key == "read" and prefix == "fill_kernel") else scale
+                            got[prefix][key] = got[prefix].get(key, 0.0) + float(r["Counter_Value"]) * 1024.0 * k_scale
                             seen += 1
             if seen == 0:
                 return None, f"no {counter} rows for the pattern kernels"
@@ -240,7 +245,8 @@ def measure_traffic(argv_tail, launches):
             shutil.rmtree(out, ignore_errors=True)
     per_launch = {k: {rw: int(v / passes / max(launches[k], 1)) for rw, v in d.items()} for k, d in got.items()}
     return per_launch, (f"measured in this run: two child `rocprofv3 --pmc` runs of the same command (FETCH_SIZE, "
-                        f"WRITE_SIZE), {passes} passes each, x2 gfx950 FETCH_SIZE correction")
+                        f"WRITE_SIZE), {passes} passes each; x2 gfx950 FETCH_SIZE correction for the wide reads of validate_kernel "
+                        f"and warm_tables_kernel, x1 for the 64-byte scalar reads of fill_kernel")
 
 
 def self_launch(n, timeout_s):

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboval_hip.so")
+# OVAL_HIP_LIB names another build of the same library (A/B measurements of two builds on one box)
+LIB_PATH = os.environ.get("OVAL_HIP_LIB") or os.path.join(_HERE, "liboval_hip.so")
 
 UNIT = 256
 NO_BAD_UNIT = 0xFFFFFFFF
