@@ -106,6 +106,9 @@ func Generate(dataSize, workerID int, bucketName string, obj *object.Object) ([]
 	if dataSize < 0 {
 		return nil, fmt.Errorf("negative data size")
 	}
+	if twoStep && dataSize <= twoStepMaxBody {
+		return generateTwoStep(dataSize, workerID, bucketName, obj) // twostep_hip.go: no thread blocked in the library
+	}
 	data := make([]byte, dataSize)
 	var out *C.uint8_t
 	if dataSize > 0 {
@@ -164,6 +167,9 @@ func ovalGoRead(user unsafe.Pointer, p *C.uint8_t, n C.size_t) C.size_t {
 // staging memory by the library (through ovalGoRead) and validated on the
 // device; the returned error text is the reference's.
 func Valid(workerID int, expectedBucketName string, obj *object.Object, reader io.Reader) error {
+	if twoStep && obj.Size <= twoStepMaxBody {
+		return validTwoStep(workerID, expectedBucketName, obj, reader) // twostep_hip.go
+	}
 	h := cgo.NewHandle(&readerBox{r: reader})
 	defer h.Delete()
 	user := (*cgo.Handle)(C.malloc(C.size_t(unsafe.Sizeof(h))))

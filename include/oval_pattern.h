@@ -131,6 +131,31 @@ int oval_pattern_valid_batch(size_t n, const int64_t* worker_ids, const char* co
                              const uint8_t* const* bodies, const size_t* body_lens,
                              int* rcs, char* errs, size_t err_stride);
 
+/* Generate / Valid in two steps (no counterpart in the reference), for a host
+ * whose own tasks are cheaper to park than an OS thread is to put to sleep: a
+ * goroutine that calls *_begin, yields to the Go scheduler between polls and
+ * collects with oval_pattern_poll never blocks its thread in the library, and the
+ * two sleeps and two wake-ups of a blocking call (which cost a 16-core host more
+ * than the device work takes) are not paid.  *_begin checks the arguments, hands
+ * the device work to the micro-batcher (oval_pattern_set_batching must be on) and
+ * returns OVAL_OK with a handle.  oval_pattern_poll returns
+ * OVAL_PATTERN_PENDING while the call is under way, else once the value the
+ * blocking call would have returned (0 nil, 1 error text in err, < 0 engine
+ * failure), and frees the handle.  `out` / `body` must stay valid until then
+ * (Go: pinned with runtime.Pinner).  Every handle must be polled to its end: a
+ * staging slot is held until its jobs have been collected.  A call that cannot
+ * share a launch (micro-batching off, body over 256 KiB) is carried out inside
+ * *_begin; its first poll returns the result. */
+#define OVAL_PATTERN_PENDING 2
+typedef struct oval_pending oval_pending;
+int oval_pattern_generate_begin(int64_t data_size, int64_t worker_id, const char* bucket, size_t bucket_len,
+                                const char* key, size_t key_len, int64_t write_count, uint8_t* out,
+                                oval_pending** pending);
+int oval_pattern_valid_begin(int64_t worker_id, const char* bucket, size_t bucket_len,
+                             const char* key, size_t key_len, int64_t size, int64_t write_count,
+                             const uint8_t* body, size_t body_len, oval_pending** pending);
+int oval_pattern_poll(oval_pending* pending, char* err, size_t err_cap);
+
 /* Micro-batching of concurrent single-object calls (worker goroutines call
  * Generate / Valid one object at a time, internal/runner/worker.go:64-200):
  * while enabled, calls arriving within window_us share one device launch. */

@@ -147,6 +147,9 @@ SIGNATURES = {
     "oval_parts_release": (_int, [_vp, _i64]),
     "oval_parts_close": (None, [_vp]),
     "oval_parts_pool_stats": (None, [C.POINTER(_sz), C.POINTER(_sz)]),
+    "oval_pattern_generate_begin": (_int, [_i64, _i64, _cp, _sz, _cp, _sz, _i64, _vp, _pp]),
+    "oval_pattern_valid_begin": (_int, [_i64, _cp, _sz, _cp, _sz, _i64, _i64, _vp, _sz, _pp]),
+    "oval_pattern_poll": (_int, [_vp, _cp, _sz]),
     "oval_pattern_set_batching": (None, [_int, _int, _sz]),
     "oval_pattern_set_lanes": (None, [_int, _int]),
     "oval_pattern_set_wake_tuning": (None, [_int, _int, _int]),

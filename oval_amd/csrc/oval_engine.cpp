@@ -170,6 +170,11 @@ struct Slot {
     // bits 0-16 validate units, 17-33 fill units, 34-45 validate jobs, 46-57
     // fill jobs, bit 63 closed (set whenever the slot is not the open one).
     std::atomic<uint64_t> ticket{kClosed};
+    // Jobs whose callers do not wait inside the library (submit / try_complete): they watch `completed`,
+    // which takes the value of `batch_seq` when the batch is over, instead of a wake word of their own.
+    uint32_t batch_seq = 0;               // counts the batches of this slot as the open slot; fixed while a batch has readers
+    std::atomic<uint32_t> completed{0};
+    std::atomic<uint32_t> n_async{0};     // such jobs in the batch being assembled
     std::atomic<uint32_t> written{0};     // callers that have finished writing their descriptor / body
     std::atomic<int> readers{0};          // callers that have not collected their outcome yet
     // One futex word per job (validate jobs first, then fill jobs), each in a
@@ -366,6 +371,7 @@ void reset_batch(Slot& s)
 {
     s.n_fill = 0; s.n_val = 0; s.fill_bytes = 0; s.val_bytes = 0; s.max_job_bytes = 0;
     s.written.store(0, std::memory_order_relaxed);
+    s.n_async.store(0, std::memory_order_relaxed);
     s.failed = false;
     s.err.clear();
 }
@@ -565,6 +571,7 @@ bool install_open(std::unique_lock<std::mutex>& lk, Pipeline& g, Slot* c)
         if (g.open.load(std::memory_order_relaxed) || !g.enabled.load(std::memory_order_relaxed) || g.stop) return false;
     }
     reset_batch(*c);
+    c->batch_seq++;
     c->ticket.store(0, std::memory_order_relaxed);
     g.open.store(c, std::memory_order_release);
     return true;
@@ -648,6 +655,20 @@ void process_batch(Slot* s, uint64_t t, bool blocking, uint64_t* phase_ns)
     if (rc) note_failure(*s);
     else s->pipe->batch_ns = (3 * s->pipe->batch_ns + (t3 - t1)) / 4;   // (lanes race on this estimate; any of their values will do)
     s->readers.store((int)n_jobs, std::memory_order_relaxed);
+    // Jobs submitted without a waiting caller learn of the end from `completed`.  Nobody wakes on their
+    // behalf, so they cannot be links of the wake tree: a batch that holds any of them has every sleeping
+    // caller woken from here (all jobs are roots), a batch of nothing else needs no wake-up at all.
+    const uint32_t n_async = s->n_async.load(std::memory_order_acquire);
+    if (n_async != 0) {
+        s->wake_fanout = 0;
+        s->wake_roots = n_async == n_jobs ? 0 : (int)n_jobs;
+        const uint32_t seq = s->batch_seq;
+        s->completed.store(seq, std::memory_order_release);     // (the slot may be reopened from here on)
+        if (n_async == n_jobs) {
+            if (phase_ns) { phase_ns[0] = t1 - t0; phase_ns[1] = t2 - t1; phase_ns[2] = t3 - t2; phase_ns[3] = now_ns() - t3; }
+            return;
+        }
+    }
     wake_roots(s);
     if (phase_ns) {
         phase_ns[0] = t1 - t0; phase_ns[1] = t2 - t1; phase_ns[2] = t3 - t2; phase_ns[3] = now_ns() - t3;
@@ -1152,6 +1173,89 @@ void execute(Job& job)
         job.res = s->res_host[idx];
     }
     if (s->readers.fetch_sub(1, std::memory_order_acq_rel) == 1) release_slot(s);
+}
+
+// ---------------------------------------------------------------------------
+// jobs whose callers do not wait inside the library
+// ---------------------------------------------------------------------------
+// A host language with cheap tasks of its own (goroutines) loses more to the two sleeps and two wake-ups
+// of a blocking call than the device takes for the work: submit() reserves and writes the job like
+// execute() does and returns; try_complete() says whether the batch is over and, once, collects the
+// outcome.  The job shares its launch with whatever else arrived, blocking callers included.
+int submit(Job& job, Ticket& t)
+{
+    t.slot = nullptr;
+    const uint64_t units = job.desc.n_units;
+    const size_t bytes = (size_t)units * kUnit;
+    if (bytes == 0 || bytes > kSharedJobMax) return -1;
+    Pipeline& g = engine_for(job.desc.worker_id);
+    if (!g.enabled.load(std::memory_order_acquire)) return -1;
+    const int ushift = job.is_fill ? kFillUnitsShift : kValUnitsShift;
+    const int jshift = job.is_fill ? kFillJobsShift : kValJobsShift;
+    Slot* s = nullptr;
+    uint64_t before = 0;
+    // The open slot as it is right now, or none.  A caller that does not wait inside the library is never
+    // made to wait for a slot here: it may itself hold jobs that keep slots busy until it collects them.
+    for (int attempt = 0; attempt < 4 && !s; ++attempt) {
+        Slot* c = g.open.load(std::memory_order_acquire);
+        if (!c) {
+            std::unique_lock<std::mutex> lk(g.mu);
+            if (!g.enabled.load(std::memory_order_relaxed)) return -1;
+            if (!g.open.load(std::memory_order_relaxed)) {
+                if (g.free_slots.empty()) return g.quarantined == kSlots ? -1 : 0;
+                Slot* f = pop_free_locked(g, true);
+                if (!install_open(lk, g, f)) {
+                    g.free_slots.push_back(f);
+                    if (f->failed) return -1;
+                }
+            }
+            continue;
+        }
+        uint64_t tk = c->ticket.load(std::memory_order_acquire);
+        while (!(tk & kClosed)) {
+            if (((tk >> ushift) & kUnitsMask) + units > kSharedUnits || ((tk >> jshift) & kJobsMask) + 1 > kSharedJobs) return 0;
+            if (c->ticket.compare_exchange_weak(tk, tk + (units << ushift) + (1ull << jshift), std::memory_order_acq_rel,
+                                                std::memory_order_acquire)) {
+                s = c;
+                before = tk;
+                break;
+            }
+        }
+    }
+    if (!s) return 0;
+    const uint32_t idx = (uint32_t)((before >> jshift) & kJobsMask);
+    const size_t off = (size_t)((before >> ushift) & kUnitsMask) * kUnit;
+    t.slot = s;
+    t.batch_seq = s->batch_seq;                                  // fixed from the reservation until this job has been collected
+    t.idx = idx;
+    t.off = off;
+    job.desc.body_offset = off;
+    (job.is_fill ? s->fdescs : s->vdescs)[idx] = job.desc;
+    if (!job.is_fill) std::memcpy(s->up_host + off, job.in, bytes);
+    s->n_async.fetch_add(1, std::memory_order_release);
+    s->written.fetch_add(1, std::memory_order_release);
+    if (t_jobs(before) == 0) {
+        { std::lock_guard<std::mutex> lk(g.mu); }                // see execute(): orders this against a lane about to sleep
+        g.lane_cv.notify_one();
+    }
+    return 1;
+}
+
+bool try_complete(Ticket& t, Job& job)
+{
+    Slot* s = static_cast<Slot*>(t.slot);
+    if (s->completed.load(std::memory_order_acquire) != t.batch_seq) return false;
+    if (s->failed) {
+        job.failed = true;
+        job.err = s->err;
+    } else if (job.is_fill) {
+        std::memcpy(job.out, s->down_host + t.off, (size_t)job.desc.n_units * kUnit);
+    } else {
+        job.res = s->res_host[t.idx];
+    }
+    t.slot = nullptr;
+    if (s->readers.fetch_sub(1, std::memory_order_acq_rel) == 1) release_slot(s);
+    return true;
 }
 
 void set_lanes(int lanes, int blocking)

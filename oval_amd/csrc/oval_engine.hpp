@@ -41,6 +41,21 @@ void run(Job* const* jobs, size_t n);
 // enough to share a slot), else as a batch of one.
 void execute(Job& job);
 
+// The same without a caller waiting inside the library.  submit() places the job in the micro-batcher's
+// open slot (the validate body is copied then; `out` must stay valid until the job has been collected) and
+// returns 1.  0: no room right now (every slot busy, the open one full): nothing was done, try again later —
+// never by waiting inside the library, since the caller may itself hold the jobs that keep the slots busy.
+// -1: the job cannot travel this way at all (micro-batching off, the job too large): call execute().  try_complete()
+// returns false while the batch is under way; true once, with the outcome in `job`, after which the
+// ticket is spent.  Every submitted job must be collected: its staging slot is held until then.
+struct Ticket {
+    void* slot = nullptr;
+    uint32_t batch_seq = 0, idx = 0;
+    size_t off = 0;
+};
+int submit(Job& job, Ticket& t);
+bool try_complete(Ticket& t, Job& job);
+
 void set_batching(bool enable, int window_us, size_t max_bytes);
 // Lanes = batches in flight at once (1..8); blocking = lanes sleep on an
 // interrupt while their batch is on the device instead of polling.  Takes

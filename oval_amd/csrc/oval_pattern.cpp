@@ -649,6 +649,83 @@ Error ValidBytes(int64_t workerID, const std::string& expectedBucketName, const 
     return finish_valid(workerID, obj, body, st, job);
 }
 
+// ---------------------------------------------------------------------------
+// Generate / Valid in two steps, for callers that have something better to do
+// than sleep while the device works (a goroutine that yields to its scheduler)
+// ---------------------------------------------------------------------------
+struct Pending {
+    bool is_generate = false, submitted = false, started = false, finished = false;
+    Job job;
+    engine::Ticket ticket;
+    ValidState st;
+    object::Object obj;
+    int64_t workerID = 0;
+    const uint8_t* body = nullptr;
+    Error result = Error::Nil();
+};
+
+namespace {
+// The device step of a pending call: through the micro-batcher without waiting when it can take the job,
+// else here and now.
+// (no room in the micro-batcher right now: the job stays where it is and the next Poll offers it again)
+void pending_start(Pending* p)
+{
+    const int how = engine::submit(p->job, p->ticket);
+    if (how == 0) return;
+    p->started = true;
+    if (how > 0) p->submitted = true;
+    else execute(p->job);
+}
+}  // namespace
+
+Pending* GenerateBegin(int64_t dataSize, int64_t workerID, const std::string& bucketName, const object::Object* obj,
+                       uint8_t* out)
+{
+    Pending* p = new Pending;
+    p->is_generate = true;
+    p->result = prepare_generate(dataSize, workerID, bucketName, obj, out, p->job);
+    if (!p->result.nil() || p->job.desc.n_units == 0) {
+        p->finished = true;
+        return p;
+    }
+    pending_start(p);
+    return p;
+}
+
+Pending* ValidBegin(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
+                    const uint8_t* body, size_t bodyLen)
+{
+    Pending* p = new Pending;
+    p->obj = *obj;
+    p->workerID = workerID;
+    p->body = body;
+    p->result = prepare_valid(workerID, expectedBucketName, &p->obj, body, bodyLen, p->st, p->job);
+    if (!p->result.nil() || !p->st.has_job) {
+        if (p->result.nil()) p->result = finish_valid(workerID, &p->obj, body, p->st, p->job);
+        p->finished = true;
+        return p;
+    }
+    pending_start(p);
+    return p;
+}
+
+bool Poll(Pending* p, Error* result)
+{
+    if (!p->finished) {
+        if (!p->started) {
+            pending_start(p);
+            if (!p->started) return false;
+        }
+        if (p->submitted && !engine::try_complete(p->ticket, p->job)) return false;
+        if (p->is_generate) p->result = p->job.failed ? engine_error(p->job) : Error::Nil();
+        else p->result = finish_valid(p->workerID, &p->obj, p->body, p->st, p->job);
+        p->finished = true;
+    }
+    if (result) *result = p->result;
+    delete p;
+    return true;
+}
+
 namespace {
 
 std::atomic<size_t> g_stream_chunk_bytes{32u << 20};
@@ -1051,6 +1128,36 @@ void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes)
 void oval_pattern_set_lanes(int lanes, int blocking_sync) { oval::pattern::SetBatchLanes(lanes, blocking_sync); }
 
 void oval_pattern_set_direct_callers(int callers) { oval::pattern::SetDirectCallers(callers); }
+
+int oval_pattern_generate_begin(int64_t data_size, int64_t worker_id, const char* bucket, size_t bucket_len,
+                                const char* key, size_t key_len, int64_t write_count, uint8_t* out,
+                                oval_pending** pending)
+{
+    if (!pending) return oval_internal_fail(OVAL_E_INVALID, "pending is NULL");
+    const oval::object::Object obj = make_obj(key, key_len, 0, write_count);
+    *pending = reinterpret_cast<oval_pending*>(
+        oval::pattern::GenerateBegin(data_size, worker_id, std::string(bucket ? bucket : "", bucket_len), &obj, out));
+    return OVAL_OK;
+}
+
+int oval_pattern_valid_begin(int64_t worker_id, const char* bucket, size_t bucket_len, const char* key, size_t key_len,
+                             int64_t size, int64_t write_count, const uint8_t* body, size_t body_len,
+                             oval_pending** pending)
+{
+    if (!pending) return oval_internal_fail(OVAL_E_INVALID, "pending is NULL");
+    const oval::object::Object obj = make_obj(key, key_len, size, write_count);
+    *pending = reinterpret_cast<oval_pending*>(
+        oval::pattern::ValidBegin(worker_id, std::string(bucket ? bucket : "", bucket_len), &obj, body, body_len));
+    return OVAL_OK;
+}
+
+int oval_pattern_poll(oval_pending* pending, char* err, size_t err_cap)
+{
+    if (!pending) return oval_internal_fail(OVAL_E_INVALID, "pending is NULL");
+    oval::Error e = oval::Error::Nil();
+    if (!oval::pattern::Poll(reinterpret_cast<oval::pattern::Pending*>(pending), &e)) return OVAL_PATTERN_PENDING;
+    return put_error(e, err, err_cap);
+}
 int oval_pattern_init_engines(const int* devices, int n) { return oval::pattern::InitEngines(devices, n); }
 int oval_pattern_engine_count(void) { return oval::pattern::EngineCount(); }
 void oval_pattern_set_device_timeout(uint64_t ms) { (void)oval_set_device_timeout_ms(ms); }

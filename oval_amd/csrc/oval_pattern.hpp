@@ -150,6 +150,20 @@ struct ValidItem {
 std::vector<Error> GenerateBatch(const std::vector<GenerateItem>& items);
 std::vector<Error> ValidBatch(const std::vector<ValidItem>& items);
 
+// Generate / Valid in two steps (no counterpart in the reference): Begin checks the arguments, hands the
+// device work to the micro-batcher and returns at once; Poll says whether the call is over and, when it is,
+// returns what Generate / Valid would have returned and frees the handle (true exactly once).  `out`
+// (Generate) and `body` (Valid: the error text quotes the unit it found) must stay valid until then.  For a
+// host language whose own tasks are cheaper to park than an OS thread is to put to sleep: two sleeps and two
+// wake-ups per blocking call cost the host more than the device work takes.  With micro-batching off, or
+// for a body over 256 KiB, Begin does the whole call and the first Poll returns true.
+struct Pending;
+Pending* GenerateBegin(int64_t dataSize, int64_t workerID, const std::string& bucketName, const object::Object* obj,
+                       uint8_t* out);
+Pending* ValidBegin(int64_t workerID, const std::string& expectedBucketName, const object::Object* obj,
+                    const uint8_t* body, size_t bodyLen);
+bool Poll(Pending* p, Error* result);
+
 // pattern.go:136-180
 Error validDataUnit(int64_t unitCount, int64_t workerID, const std::string& expectedBucketName,
                     const object::Object* obj, const uint8_t* data /* 256 bytes */);

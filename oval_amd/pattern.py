@@ -235,6 +235,51 @@ def validDataUnit(unitCount: int, workerID: int, expectedBucketName, obj: Object
     _raise(rc, err)
 
 
+class PendingCall:
+    """Generate / Valid in two steps: begin returns at once, `poll()` returns
+    False while the device works and True once the call is over, after which
+    `result()` is the bytes (Generate) / None (Valid) or raises what the blocking
+    call would have raised."""
+
+    def __init__(self, handle, keep, out=None, size=0):
+        self._h, self._keep, self._out, self._size = handle, keep, out, size
+        self._rc, self._text = None, None
+
+    def poll(self) -> bool:
+        if self._rc is None:
+            err = C.create_string_buffer(_ERR_CAP)
+            rc = _lib.lib().oval_pattern_poll(self._h, err, _ERR_CAP)
+            if rc == 2:
+                return False
+            self._rc, self._text, self._h = rc, err, None
+        return True
+
+    def result(self):
+        while not self.poll():
+            pass
+        _raise(self._rc, self._text)
+        return self._out[:self._size].tobytes() if self._out is not None else None
+
+
+def GenerateBegin(dataSize: int, workerID: int, bucketName, obj: Object) -> PendingCall:
+    b, k = _b(bucketName), _b(obj.Key)
+    out = np.empty(max(dataSize, 1), dtype=np.uint8)
+    h = C.c_void_p()
+    _lib.check(_lib.lib().oval_pattern_generate_begin(dataSize, workerID, b, len(b), k, len(k), obj.WriteCount,
+                                                      out.ctypes.data, C.byref(h)))
+    return PendingCall(h, (b, k), out, dataSize)
+
+
+def ValidBegin(workerID: int, expectedBucketName, obj: Object, body) -> PendingCall:
+    b, k = _b(expectedBucketName), _b(obj.Key)
+    arr = np.ascontiguousarray(np.frombuffer(_b(body), dtype=np.uint8) if not isinstance(body, np.ndarray) else body,
+                               dtype=np.uint8)
+    h = C.c_void_p()
+    _lib.check(_lib.lib().oval_pattern_valid_begin(workerID, b, len(b), k, len(k), obj.Size, obj.WriteCount,
+                                                   arr.ctypes.data if arr.size else None, arr.size, C.byref(h)))
+    return PendingCall(h, (b, k, arr))
+
+
 def set_batching(enable: bool, window_us: int = 0, max_bytes: int = 64 << 20) -> None:
     """Coalesce concurrent Generate / Valid calls from different threads into
     shared device launches (results are unchanged)."""

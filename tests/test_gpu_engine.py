@@ -192,3 +192,71 @@ def test_two_engines_in_one_process(oracle):
         pattern.init_engines([0])
     assert pattern.engine_count() == 1
     _check(oracle, items[:5], [_cycle(pattern, it) for it in items[:5]])
+
+
+def test_calls_in_two_steps_return_what_the_blocking_calls_return(oracle):
+    """GenerateBegin / ValidBegin + poll: the job travels in a shared launch while
+    the caller is free to do something else; outcomes, error texts included, are
+    those of Generate / Valid (held to the oracle).  Two-step calls and blocking
+    calls from threads share launches; with micro-batching off a two-step call is
+    carried out at once."""
+    from oval_amd import pattern
+    from oval_amd.object import Object
+
+    pattern.set_clock(T0)
+    rng = np.random.default_rng(77)
+    items = _objects(rng, 400, oracle)
+
+    def two_step(batch):
+        gens = [pattern.GenerateBegin(size, wid, bucket, obj) for size, wid, bucket, obj in batch]
+        bodies = [g.result() for g in gens]
+        vals, expect = [], []
+        for i, ((size, wid, bucket, obj), body) in enumerate(zip(batch, bodies)):
+            body = bytearray(body)
+            if i % 4 == 1:
+                body[int(rng.integers(0, size))] ^= 1 << int(rng.integers(0, 8))
+            if i % 7 == 2:
+                body = body[:int(rng.integers(0, size))]
+            if i % 11 == 3:
+                obj = Object(obj.Key, obj.Size, obj.WriteCount + 1)
+            vals.append(pattern.ValidBegin(wid, bucket, obj, bytes(body)))
+            expect.append(oracle.valid(wid, bucket, obj.Key, obj.Size, obj.WriteCount, bytes(body))[2])
+        got = []
+        for v in vals:
+            try:
+                v.result()
+                got.append(None)
+            except pattern.PatternError as e:
+                got.append(str(e))
+        return bodies, got, expect
+
+    b0, j0 = pattern.batching_stats()
+    pattern.set_direct_callers(0)
+    pattern.set_batching(True, window_us=300)
+    try:
+        bodies, got, expect = two_step(items[:200])
+        b1, j1 = pattern.batching_stats()
+        assert 200 < j1 - j0 <= 400                      # (a body cut to under one unit has no device work)
+        assert b1 - b0 < (j1 - j0) // 4, "two-step calls did not share launches"
+        # blocking callers on threads and two-step calls in the same launches
+        with ThreadPoolExecutor(12) as ex:
+            fut = ex.map(lambda it: _cycle(pattern, it), items[200:320])
+            bodies2, got2, expect2 = two_step(items[320:])
+            results = list(fut)
+        _check(oracle, items[200:320], results)
+    finally:
+        pattern.set_direct_callers(16)
+        pattern.set_batching(False)
+    for (size, wid, bucket, obj), body in zip(items[:200] + items[320:], bodies + bodies2):
+        assert body == oracle.generate(size, wid, bucket, obj.Key, obj.WriteCount, T0)
+    assert got == expect and got2 == expect2
+    assert sum(e is not None for e in expect) > 40
+    # micro-batching off: Begin does the whole call
+    g = pattern.GenerateBegin(items[0][0], items[0][1], items[0][2], items[0][3])
+    assert g.poll() and g.result() == bodies[0]
+    # argument errors surface at the first poll, as Generate would have returned them
+    bad = pattern.GenerateBegin(300, 1, "b", Object("k", 300, 1))
+    with pytest.raises(pattern.PatternError, match="generated data size is wrong"):
+        bad.result()
+    empty = pattern.ValidBegin(1, "b", Object("k", 0, 1), b"")
+    assert empty.result() is None

@@ -22,6 +22,7 @@
  */
 #define _POSIX_C_SOURCE 200809L
 #include <pthread.h>
+#include <sched.h>
 #include <stdatomic.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -149,6 +150,23 @@ static void* worker(void* argp)
         rc = valid_through_reader(wid, bucket, key, size, wc, data, (size_t)size - 100, text);
         CHECK(rc == 1 && strncmp(text, "could not read some data. (expected: 256byte, actual: 156byte)\n", 63) == 0,
               "short body: rc %d text %.80s", rc, text);
+        /* the same put-cycle in two steps, as twostep_hip.go does it: begin, yield between polls, collect */
+        {
+            uint8_t* again = malloc((size_t)size);
+            oval_pending* h = NULL;
+            rc = oval_pattern_generate_begin(size, wid, bucket.p, bucket.n, key.p, key.n, wc, again, &h);
+            if (rc == 0)
+                while ((rc = oval_pattern_poll(h, text, ERR_TEXT_CAP)) == OVAL_PATTERN_PENDING) sched_yield();
+            const int same = rc == 0 && memcmp(again, data, (size_t)size) == 0;
+            again[5 * 256 + 36] ^= 0x20;                         /* worker ID of unit 5 */
+            int rc2 = oval_pattern_valid_begin(wid, bucket.p, bucket.n, key.p, key.n, size, wc, again, (size_t)size, &h);
+            if (rc2 == 0)
+                while ((rc2 = oval_pattern_poll(h, text, ERR_TEXT_CAP)) == OVAL_PATTERN_PENDING) sched_yield();
+            free(again);
+            atomic_fetch_add(&g_calls, 2);
+            CHECK(same, "two-step generate: rc %d, body %s", rc, rc == 0 ? "differs" : "missing");
+            CHECK(rc2 == 1 && strncmp(text, "- WorkerID is wrong.", 20) == 0, "two-step valid: rc %d text %.60s", rc2, text);
+        }
         /* validDataUnit on one unit of it */
         rc = oval_pattern_valid_data_unit(2, wid, bucket16.p, bucket16.n, key.p, key.n, wc, data + 512, text, ERR_TEXT_CAP);
         CHECK(rc == 0, "valid_data_unit rc %d: %s", rc, text);

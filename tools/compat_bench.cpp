@@ -7,6 +7,10 @@
 //
 //   compat_bench [seconds] [threads,threads,...] [lanes,lanes,...] [blocking 0|1|2 (2 = both)] [skip the unbatched run 0|1]
 //                [wake fan-out] [wake roots] [caller spin ns] [completion by flag 1|0] [direct below N callers]
+// Environment: COMPAT_SIZES=min,max (object sizes, default 4096,16384); COMPAT_SPIN=ns,callers;
+// COMPAT_ASYNC=W: every thread carries W workers and steps them round-robin through GenerateBegin / ValidBegin / Poll
+// instead of blocking in Generate / Valid — what a goroutine per worker does on the Go scheduler when the binding yields
+// between polls (threads x W logical workers on `threads` OS threads, none of which ever sleeps in the library).
 #include <sys/resource.h>
 
 #include <atomic>
@@ -22,6 +26,49 @@
 
 using namespace oval;
 
+static int64_t g_min_size = 4096, g_max_size = 16384;
+static int g_async_workers = 0;
+
+// One worker of the two-step mode: where it is in its put-cycle.
+struct Fiber {
+    enum { IDLE, GENERATING, VALIDATING } state = IDLE;
+    std::vector<object::Object> objs;
+    std::vector<uint8_t> body;
+    object::Object* o = nullptr;
+    pattern::Pending* pending = nullptr;
+    int64_t wid = 0;
+    uint64_t i = 0;
+};
+
+// One step of a worker; true when a put-cycle has just been completed.
+static bool step(Fiber& f, std::atomic<uint64_t>& errors, uint64_t& bytes)
+{
+    Error e = Error::Nil();
+    switch (f.state) {
+    case Fiber::IDLE: {
+        f.o = &f.objs[f.i++ % f.objs.size()];
+        f.o->Size = pattern::DecideSize(g_min_size, g_max_size).first;
+        f.o->WriteCount++;
+        f.body.resize((size_t)f.o->Size);
+        f.pending = pattern::GenerateBegin(f.o->Size, f.wid, "test-bucket", f.o, f.body.data());
+        f.state = Fiber::GENERATING;
+        return false;
+    }
+    case Fiber::GENERATING:
+        if (!pattern::Poll(f.pending, &e)) return false;
+        if (!e.nil()) { errors++; f.state = Fiber::IDLE; return false; }
+        f.pending = pattern::ValidBegin(f.wid, "test-bucket", f.o, f.body.data(), f.body.size());
+        f.state = Fiber::VALIDATING;
+        return false;
+    default:
+        if (!pattern::Poll(f.pending, &e)) return false;
+        if (!e.nil()) errors++;
+        bytes += 2 * (uint64_t)f.o->Size;
+        f.state = Fiber::IDLE;
+        return true;
+    }
+}
+
 static void run(int n_threads, double seconds, bool batching, int lanes, int blocking)
 {
     pattern::SetBatchLanes(lanes, blocking);
@@ -36,13 +83,31 @@ static void run(int n_threads, double seconds, bool batching, int lanes, int blo
     std::atomic<uint64_t> ops{0}, bytes{0}, errors{0};
     std::vector<std::thread> ths;
     for (int t = 0; t < n_threads; ++t) {
+        if (g_async_workers > 0 && batching) {
+            ths.emplace_back([&, t] {
+                std::vector<Fiber> fibers((size_t)g_async_workers);
+                for (int w = 0; w < g_async_workers; ++w) {
+                    const int id = t * g_async_workers + w;
+                    for (int j = 0; j < 64; ++j) fibers[(size_t)w].objs.push_back(object::NewObject(((int64_t)id << 24) + j));
+                    fibers[(size_t)w].wid = 0x561B + id;
+                }
+                uint64_t my_ops = 0, my_bytes = 0;
+                while (!stop.load(std::memory_order_relaxed))
+                    for (Fiber& f : fibers) my_ops += step(f, errors, my_bytes) ? 1 : 0;
+                for (Fiber& f : fibers)                          // every call under way is collected
+                    while (f.state != Fiber::IDLE) (void)step(f, errors, my_bytes);
+                ops += my_ops;
+                bytes += my_bytes;
+            });
+            continue;
+        }
         ths.emplace_back([&, t] {
             std::vector<object::Object> objs;
             for (int j = 0; j < 256; ++j) objs.push_back(object::NewObject(((int64_t)t << 24) + j));
             uint64_t i = 0, my_ops = 0, my_bytes = 0;
             while (!stop.load(std::memory_order_relaxed)) {
                 object::Object& o = objs[i++ % objs.size()];
-                auto sz = pattern::DecideSize(4096, 16384);
+                auto sz = pattern::DecideSize(g_min_size, g_max_size);
                 o.Size = sz.first;
                 o.WriteCount++;
                 auto body = pattern::Generate(o.Size, 0x561B + t, "test-bucket", &o);
@@ -64,6 +129,7 @@ static void run(int n_threads, double seconds, bool batching, int lanes, int blo
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     uint64_t b = 0, j = 0;
     pattern::MicroBatchingStats(&b, &j);
+    if (g_async_workers > 0 && batching) std::printf("two-step calls, %d workers per thread: ", g_async_workers);
     std::printf("threads %3d  batching %-3s lanes %d %-8s: %9.0f put-cycles/s  %8.3f GB/s generate+validate  errors %llu  jobs/launch %.1f\n",
                 n_threads, batching ? "on" : "off", lanes, blocking ? "blocking" : "polling", ops / dt, bytes / dt / 1e9,
                 (unsigned long long)errors.load(), b > b0 ? (double)(j - j0) / (double)(b - b0) : 0.0);
@@ -114,6 +180,13 @@ int main(int argc, char** argv)
         std::printf("caller spin %d ns, at most %d callers polling (-1 = default)\n", ns, budget);
     }
     std::printf("engines: %d\n", pattern::EngineCount());
+    if (const char* e = std::getenv("COMPAT_SIZES")) {
+        long long lo = 4096, hi = 16384;
+        std::sscanf(e, "%lld,%lld", &lo, &hi);
+        g_min_size = lo; g_max_size = hi;
+        std::printf("object sizes %lld - %lld bytes\n", lo, hi);
+    }
+    if (const char* e = std::getenv("COMPAT_ASYNC")) g_async_workers = atoi(e);
     if (argc > 10) {
         pattern::SetDirectCallers(atoi(argv[10]));
         std::printf("calls launch on their own while at most %d are under way\n", atoi(argv[10]));
