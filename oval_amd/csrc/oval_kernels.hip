@@ -454,52 +454,62 @@ __device__ __forceinline__ void w_totals_flush(unsigned long long* __restrict__ 
 
 // Exact per-field outcome of one lane's 16 bytes (pattern.go:140-170); only
 // reached for a unit that failed the 128-bit compare or whose descriptor asks
-// for the exact check.  The numeric fields are selects on the XOR of the lane's
-// bytes with its template; the one divergent branch is the TrimSpace compare of
-// a name field, taken only by a name lane whose bytes differ from the formatted
-// expected name (or whose expected name has white space at an edge, `force`):
-// a stale generation, where only the write count differs, never takes it.
-__device__ __forceinline__ uint32_t lane_field_mask(const u32x4& v, uint32_t ex, const u32x4& tmpl, uint32_t lf,
-                                                    uint32_t force, int j)
+// for the exact check.  Every field is judged by one fixed lane of a unit's
+// sixteen, and no lane judges more than two: the result is two bits,
+//   lane 0: A = bucket            lane 1: A = key, B = write count
+//   lane 2: A = offset, B = worker ID        lanes 3-15: A = filler
+// The numeric fields are compares of the XOR of the lane's bytes with its
+// template; the one divergent branch is the TrimSpace compare of a name field,
+// taken only by a name lane whose bytes differ from the formatted expected name
+// (or whose expected name has white space at an edge, `force`): a stale
+// generation, where only the write count differs, never takes it.
+__device__ __forceinline__ uint32_t lane_verdicts(const u32x4& v, uint32_t ex, const u32x4& tmpl, uint32_t lf,
+                                                  uint32_t force, int j)
 {
     const uint32_t dx = v.x ^ ex, dy = v.y ^ tmpl.y, dz = v.z ^ tmpl.z, dw = v.w ^ tmpl.w;
-    uint32_t fm = (j >= 3) ? OVAL_BAD_FILLER : 0u;
-    fm |= (j == 1 && dw != 0u) ? OVAL_BAD_WRITECNT : 0u;
-    fm |= (j == 2 && dx != 0u) ? OVAL_BAD_OFFSET : 0u;
-    fm |= (j == 2 && (dy | force) != 0u) ? OVAL_BAD_WORKER : 0u;    // force: worker ID outside uint32
+    if (j >= 3) return 1u;                                       // a filler lane is only here because its bytes differ
+    if (j == 2) return (dx != 0u ? 1u : 0u) | ((dy | force) != 0u ? 2u : 0u);    // force: worker ID outside uint32
+    uint32_t ab = (j == 1 && dw != 0u) ? 2u : 0u;
     const uint32_t name_diff = dx | dy | dz | (j == 0 ? dw : 0u);    // bucket: 16 bytes, key: the first 12
-    if (j < 2 && (name_diff | force) != 0u) {
+    if ((name_diff | force) != 0u) {
         const int width = j == 0 ? 16 : 12;
         const int len = (int)((j == 0 ? lf : lf >> 8) & 0xFFu);
         if (!trimmed_equals([&](int i) { return reg_byte(v, i); }, width, [&](int i) { return reg_byte(tmpl, i); }, len))
-            fm |= j == 0 ? OVAL_BAD_BUCKET : OVAL_BAD_KEY;
+            ab |= 1u;
     }
-    return fm;
+    return ab;
+}
+
+// Where a lane's two verdicts are counted in WTotals::fields (see there): shift of A | shift of B << 8.
+__device__ __forceinline__ uint32_t lane_field_slots(int j)
+{
+    return j == 0 ? 0u : j == 1 ? (6u | 12u << 8) : j == 2 ? (18u | 24u << 8) : 0u;   // (filler lanes: never read back)
 }
 
 // Exact verdict for the lanes flagged `bad` in one wavefront instruction (four
-// units, the flagged ones all inside object w).  Every field is judged by one
-// fixed lane of a unit's sixteen (bucket: lane 0; key and write count: lane 1;
-// offset and worker: lane 2; filler: lanes 3-15), so one ballot per field puts
-// the verdicts of all four units into a scalar register, at bit 16 u + that lane;
-// shifted down to bit 16 u they combine with scalar ORs: no cross-lane traffic.
+// units, the flagged ones all inside object w).  Two ballots put the verdicts of
+// all four units into scalar registers, A and B of lane l of unit u at bit
+// 16 u + l; shifted down to bit 16 u the five reference fields combine with
+// scalar ANDs and ORs: no cross-lane traffic.  (Six ballots, one per field, cost
+// a batch whose every unit is bad 5 % more; counting the fields with scalar
+// population counts of the ballots instead of in a vector register cost 3 %.)
 __device__ __forceinline__ void w_handle_bad(const u32x4& v, uint32_t ex, const u32x4& tmpl, uint32_t lf,
-                                             uint32_t force, bool bad, int j, uint32_t g4, WRun& r, WTotals& t)
+                                             uint32_t force, bool bad, int j, uint32_t slots, uint32_t g4, WRun& r,
+                                             WTotals& t)
 {
-    const uint32_t fm = bad ? lane_field_mask(v, ex, tmpl, lf, force, j) : 0u;
-    const unsigned long long bb = __ballot((fm & OVAL_BAD_BUCKET) != 0u);
-    const unsigned long long bk = __ballot((fm & OVAL_BAD_KEY) != 0u) >> 1;
-    const unsigned long long bw = __ballot((fm & OVAL_BAD_WRITECNT) != 0u) >> 1;
-    const unsigned long long bo = __ballot((fm & OVAL_BAD_OFFSET) != 0u) >> 2;
-    const unsigned long long bi = __ballot((fm & OVAL_BAD_WORKER) != 0u) >> 2;
-    const unsigned long long bf = __ballot((fm & OVAL_BAD_FILLER) != 0u);
+    const uint32_t ab = bad ? lane_verdicts(v, ex, tmpl, lf, force, j) : 0u;
+    const unsigned long long A = __ballot((ab & 1u) != 0u), B = __ballot((ab & 2u) != 0u);
+    constexpr unsigned long long m0 = 0x0001000100010001ull;
+    const unsigned long long bb = A & m0, bk = (A >> 1) & m0, bo = (A >> 2) & m0;
+    const unsigned long long bw = (B >> 1) & m0, bi = (B >> 2) & m0;
+    const unsigned long long bf = A & 0xFFF8FFF8FFF8FFF8ull;
     const unsigned long long refu = bb | bk | bw | bo | bi;    // bit 16 u: unit u has a reference-visible mismatch
     // bit 16 u + 15 of `fu`: some filler lane of unit u is set (a carry out of the low 15 bits, or bit 15 itself)
     unsigned long long fu = ((bf & 0x7FFF7FFF7FFF7FFFull) + 0x7FFF7FFF7FFF7FFFull) | bf;
-    fu = (fu >> 15) & 0x0001000100010001ull;
+    fu = (fu >> 15) & m0;
     const unsigned long long anyu = refu | fu;
-    // this lane's own verdicts, one slot per field (the mask bits are 1, 2, 4, 8, 16)
-    t.fields += (fm & 1u) | ((fm & 2u) << 5) | ((fm & 4u) << 10) | ((fm & 8u) << 15) | ((fm & 16u) << 20);
+    // this lane's own verdicts, each in its field's slot
+    t.fields += ((ab & 1u) << (slots & 31u)) + ((ab >> 1) << (slots >> 8));
     if (refu) {
         const uint32_t sh = (uint32_t)__builtin_ctzll(refu);    // 16 x the lowest bad unit
         if (r.cnt == 0u) {                                      // units arrive in ascending order
@@ -576,17 +586,18 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     w_activate(r0, n_obj, w);
     tmpl = w_lane_template(w, j, cpat);
     force = w_lane_force(w, j);
+    const uint32_t slots = lane_field_slots(j);
     WRun run = {kNone, 0, 0, kNone};
     WTotals tot = {0, 0, 0, 0};
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t g4 = g0 + 4u * i;
         const uint32_t g = g4 + grp;
-        const u32x4 vi = i == 0 ? v[0] : i == 1 ? v[1] : i == 2 ? v[2] : v[3];
+        const u32x4 vi = v[i];
         for (;;) {
             const uint32_t ex = tmpl.x + g * gmul;
             const bool bad = (g >= w.start && g < w.end) && ((w_diff(vi, ex, tmpl, zwmask) | force) != 0u);
-            if (__any(bad)) w_handle_bad(vi, ex, tmpl, w.lf, force, bad, j, g4, run, tot);
+            if (__any(bad)) w_handle_bad(vi, ex, tmpl, w.lf, force, bad, j, slots, g4, run, tot);
             if (w.end >= g4 + 4u) break;
             w_flush(results, stripes, w, run, tot, g0, lane);
             w_fetch(descs, n_obj, w.o + 1u, r);
@@ -715,6 +726,7 @@ __device__ __forceinline__ void host_batch_job(const WRaw& r, bool is_val, uint3
     }
     const uint32_t zwmask = (j == 2) ? 0u : 0xFFFFFFFFu;       // pattern.go:172 "Skip the unix time area."
     const uint32_t force = w_lane_force(w, j);
+    const uint32_t slots = lane_field_slots(j);
     WRun run = {kNone, 0, 0, kNone};
     WTotals tot = {0, 0, 0, 0};
     // 64 units (16 KiB) per round of the workgroup: four loads per thread in flight
@@ -732,7 +744,7 @@ __device__ __forceinline__ void host_batch_job(const WRaw& r, bool is_val, uint3
             const uint32_t g = g4 + grp;
             const uint32_t ex = tmpl.x + g * gmul;
             const bool bad = g < w.end && ((w_diff(v[i], ex, tmpl, zwmask) | force) != 0u);
-            if (__any(bad)) w_handle_bad(v[i], ex, tmpl, w.lf, force, bad, j, g4, run, tot);
+            if (__any(bad)) w_handle_bad(v[i], ex, tmpl, w.lf, force, bad, j, slots, g4, run, tot);
         }
     }
     if (lane == 0) {

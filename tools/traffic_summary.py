@@ -8,8 +8,11 @@
 Counters are summed over all launches of a kernel and divided by the number of
 passes over the batch.  Both counters are in KiB.  gfx950 correction: FETCH_SIZE
 tallies the 128-byte requests of a wide coalesced streaming read at 64 bytes
-each, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact for 16-byte-per-
-lane streaming stores."""
+each, so read bytes = 2 x FETCH_SIZE x 1024 for the kernels that read that way
+(validate_kernel's bodies, the table pre-pass, the builders); the fill kernel reads
+nothing but 64-byte records with scalar loads, which the counter tallies at full
+size (tools/scalar_fetch_probe.hip), so its read bytes = FETCH_SIZE x 1024.
+WRITE_SIZE is exact for 16-byte-per-lane streaming stores."""
 import collections
 import csv
 import glob
@@ -46,7 +49,7 @@ def main():
     print("# HBM traffic per pass over the batch (%d passes), PMC counters, gfx950 corrections applied" % passes)
     out = {}
     for k in sorted(set(fetch) | set(write)):
-        rd = 2.0 * fetch.get(k, 0.0) * 1024 / passes
+        rd = (1.0 if k.startswith("fill_kernel") else 2.0) * fetch.get(k, 0.0) * 1024 / passes
         wr = write.get(k, 0.0) * 1024 / passes
         print("%-34s launches/pass %5.1f  read %15.0f B  written %15.0f B" % (
             k[:34], max(nf.get(k, 0), nw.get(k, 0)) / passes, rd, wr))
