@@ -56,6 +56,7 @@
 #include <chrono>
 #include <climits>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -182,6 +183,9 @@ struct Slot {
     // a batch do not queue on one kernel futex bucket, and is woken by its parent
     // in a tree over the batch's job numbers (see wake_children).
     std::unique_ptr<WakeWord[]> words;
+    // One byte per wake word: the job at that place has no caller waiting inside the library (submit()).  Every job
+    // writes its own byte before it counts itself in `written`.
+    std::unique_ptr<uint8_t[]> no_waiter;
     int wake_fanout = kWakeFanout, wake_roots = kWakeRoots;   // shape of the batch's wake tree, fixed when it closes
     bool failed = false;
     std::string err;
@@ -331,7 +335,10 @@ int ensure_slot(Slot& s, size_t up, size_t down, size_t jobs)
     }
     // The wake words belong to shared use, not to a capacity: a slot whose arrays grew for a batch form
     // (any job count) may become the open slot later without growing again.
-    if (jobs >= kSharedJobs && !s.words) s.words.reset(new WakeWord[2 * kSharedJobs]);
+    if (jobs >= kSharedJobs && !s.words) {
+        s.no_waiter.reset(new uint8_t[2 * kSharedJobs]());
+        s.words.reset(new WakeWord[2 * kSharedJobs]);
+    }
     return OVAL_OK;
 }
 
@@ -660,14 +667,21 @@ void process_batch(Slot* s, uint64_t t, bool blocking, uint64_t* phase_ns)
     // caller woken from here (all jobs are roots), a batch of nothing else needs no wake-up at all.
     const uint32_t n_async = s->n_async.load(std::memory_order_acquire);
     if (n_async != 0) {
+        // Only the words of jobs with a waiting caller are touched, and the walk ends with the last of them: once that
+        // caller and the pollers are through, the slot may be open again and its words and bytes belong to new jobs.
         s->wake_fanout = 0;
-        s->wake_roots = n_async == n_jobs ? 0 : (int)n_jobs;
-        const uint32_t seq = s->batch_seq;
-        s->completed.store(seq, std::memory_order_release);     // (the slot may be reopened from here on)
-        if (n_async == n_jobs) {
-            if (phase_ns) { phase_ns[0] = t1 - t0; phase_ns[1] = t2 - t1; phase_ns[2] = t3 - t2; phase_ns[3] = now_ns() - t3; }
-            return;
+        const uint32_t n_val = s->n_val, n_waiting = n_jobs - n_async;
+        WakeWord* const words = s->words.get();
+        const uint8_t* const no_waiter = s->no_waiter.get();
+        s->completed.store(s->batch_seq, std::memory_order_release);
+        for (uint32_t c = 0, woken = 0; woken < n_waiting && c < n_jobs; ++c) {
+            const uint32_t wi = c < n_val ? c : (uint32_t)kSharedJobs + (c - n_val);
+            if (no_waiter[wi]) continue;
+            ++woken;
+            complete_word(&words[wi].v);
         }
+        if (phase_ns) { phase_ns[0] = t1 - t0; phase_ns[1] = t2 - t1; phase_ns[2] = t3 - t2; phase_ns[3] = now_ns() - t3; }
+        return;
     }
     wake_roots(s);
     if (phase_ns) {
@@ -1132,6 +1146,7 @@ void execute(Job& job)
     job.desc.body_offset = off;
     (job.is_fill ? s->fdescs : s->vdescs)[idx] = job.desc;
     if (!job.is_fill) std::memcpy(s->up_host + off, job.in, bytes);
+    s->no_waiter[job.is_fill ? kSharedJobs + idx : idx] = 0;
     s->written.fetch_add(1, std::memory_order_release);
     if (t_jobs(before) == 0) {
         // first job of the batch: a lane may be asleep (taking the lock orders
@@ -1232,6 +1247,7 @@ int submit(Job& job, Ticket& t)
     job.desc.body_offset = off;
     (job.is_fill ? s->fdescs : s->vdescs)[idx] = job.desc;
     if (!job.is_fill) std::memcpy(s->up_host + off, job.in, bytes);
+    s->no_waiter[job.is_fill ? kSharedJobs + idx : idx] = 1;
     s->n_async.fetch_add(1, std::memory_order_release);
     s->written.fetch_add(1, std::memory_order_release);
     if (t_jobs(before) == 0) {
@@ -1256,6 +1272,34 @@ bool try_complete(Ticket& t, Job& job)
     t.slot = nullptr;
     if (s->readers.fetch_sub(1, std::memory_order_acq_rel) == 1) release_slot(s);
     return true;
+}
+
+// Where every engine stands, for a tool that has found its calls stuck: written without taking any lock
+// (the locks may be what is stuck), so the values are a snapshot that may be torn.
+void debug_dump(FILE* out)
+{
+    const int n = g_n_engines.load(std::memory_order_acquire);
+    std::fprintf(out, "engines %d, callers inside execute %d\n", n, g_callers.load());
+    for (int k = 0; k < n; ++k) {
+        Pipeline& g = *g_engines[k];
+        Slot* open = g.open.load(std::memory_order_acquire);
+        std::fprintf(out, "engine %d: device %d enabled %d stop %d lanes %zu free %zu quarantined %d slot_waiters %d open %ld\n", k,
+                     g.device, (int)g.enabled.load(), (int)g.stop, g.lanes.size(), g.free_slots.size(), g.quarantined,
+                     g.slot_waiters, open ? (long)(open - g.slots) : -1L);
+        for (int i = 0; i < kSlots; ++i) {
+            Slot& s = g.slots[i];
+            const uint64_t t = s.ticket.load(std::memory_order_acquire);
+            bool is_free = false;
+            for (Slot* f : g.free_slots) is_free |= f == &s;
+            if (is_free && !(s.readers.load() || t_jobs(t))) continue;
+            std::fprintf(out, "  slot %2d%s: ticket %s jobs %u+%u units %u+%u | written %u readers %d n_async %u batch_seq %u completed %u "
+                              "by_flag %d failed %d n_val %u n_fill %u\n",
+                         i, is_free ? " (free)" : "", (t & kClosed) ? "closed" : "open", t_val_jobs(t), t_fill_jobs(t),
+                         t_val_units(t), t_fill_units(t), s.written.load(), s.readers.load(), s.n_async.load(), s.batch_seq,
+                         s.completed.load(), (int)s.by_flag, (int)s.failed, s.n_val, s.n_fill);
+        }
+    }
+    std::fflush(out);
 }
 
 void set_lanes(int lanes, int blocking)

@@ -7,6 +7,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <string>
 
 #include "../../include/oval_hip.h"
@@ -86,6 +87,9 @@ void test_lose_flags(int n);
 // Staging slots set aside for good because their batch did not finish within the device time limit.
 int  quarantined_slots();
 void stats(uint64_t* batches, uint64_t* jobs);
+// A lock-free snapshot of every engine's slots (tickets, readers, completion counters), for a tool that
+// has found its calls stuck.
+void debug_dump(FILE* out);
 // Where the lane threads' time went since the last reset, summed over lanes:
 // ns waiting for callers still copying in, ns enqueueing, ns waiting for the
 // device, ns publishing + waking, ns re-taking the lock, batches, body bytes.

@@ -246,6 +246,8 @@ void SetCallerSpin(int nanos, int maxSpinners)
 
 void TestLoseFlags(int n) { engine::test_lose_flags(n); }
 
+void DebugDump(FILE* out) { engine::debug_dump(out); }
+
 int QuarantinedSlots() { return engine::quarantined_slots(); }
 
 void SetMicroBatching(bool enable, int windowMicros, size_t maxBytes)

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <string>
 #include <utility>
 #include <vector>
@@ -205,6 +206,8 @@ void SetCallerSpin(int nanos, int maxSpinners);
 // device that hangs); they end by the device time limit (oval_set_device_timeout_ms) and cost their
 // staging slots, which QuarantinedSlots counts.
 void TestLoseFlags(int n);
+// Where the engines' staging slots stand (a snapshot taken without locks), for a tool whose calls are stuck.
+void DebugDump(FILE* out);
 int  QuarantinedSlots();
 // How GenerateBatch / ValidBatch cut a large batch into sub-batches that travel through the device one
 // behind the other: at most `chunkBytes` each (0 keeps the setting; default 16 MiB), `depth` in flight

@@ -8,7 +8,8 @@
 // Workers run the reference's loop shape (DecideSize, Generate, Valid; every so
 // often a damaged body, which Valid must refuse with the write-count message; a
 // multipart-sized body through GenerateParts, its parts touched out of order; a
-// body validated through a reader that delivers it in pieces; the batch forms)
+// body validated through a reader that delivers it in pieces; the batch forms;
+// several calls in two steps under way at once, begun and polled by one thread)
 // while another thread switches micro-batching off and on.  Exit code 0 = every
 // call gave what it had to.  (A build with -Xarch_host -fsanitize=thread links,
 // but the HIP runtime finds no device under the thread sanitizer's address-space
@@ -96,6 +97,39 @@ int main(int argc, char** argv)
                     calls += 2;
                     continue;
                 }
+                if (kind >= 10 && kind < 20) {
+                    // four put-cycles in two steps, all under way at once on this one thread
+                    constexpr int kN = 4;
+                    object::Object os[kN];
+                    std::vector<uint8_t> bodies[kN];
+                    pattern::Pending* h[kN];
+                    bool hit[kN];
+                    for (int q = 0; q < kN; ++q) {
+                        os[q] = objs[(i + (uint64_t)q) % objs.size()];
+                        os[q].WriteCount += 7 + q;
+                        os[q].Size = pattern::DecideSize(4096, 16384).first;
+                        bodies[q].assign((size_t)os[q].Size, 0xEE);
+                        h[q] = pattern::GenerateBegin(os[q].Size, wid, "test-bucket", &os[q], bodies[q].data());
+                    }
+                    for (int q = 0; q < kN; ++q) {
+                        Error e = Error::Nil();
+                        while (!pattern::Poll(h[q], &e)) std::this_thread::yield();
+                        if (!e.nil()) wrong++;
+                        auto twin = pattern::Generate(os[q].Size, wid, "test-bucket", &os[q]);   // the blocking call's bytes
+                        if (!twin.second.nil() || twin.first != bodies[q]) wrong++;
+                        hit[q] = (mix(rs) & 1) != 0;
+                        if (hit[q]) bodies[q][(size_t)(mix(rs) % (uint64_t)(os[q].Size / 256)) * 256 + 30] ^= 0x10;
+                        h[q] = pattern::ValidBegin(wid, "test-bucket", &os[q], bodies[q].data(), bodies[q].size());
+                    }
+                    for (int q = 0; q < kN; ++q) {
+                        Error e = Error::Nil();
+                        while (!pattern::Poll(h[q], &e)) std::this_thread::yield();
+                        if (e.nil() == hit[q]) wrong++;
+                        if (hit[q] && e.msg.find("WriteCount is wrong") == std::string::npos) wrong++;
+                    }
+                    calls += 3 * kN;
+                    continue;
+                }
                 auto sz = pattern::DecideSize(4096, 16384);
                 o.Size = sz.first;
                 auto body = pattern::Generate(o.Size, wid, "test-bucket", &o);
@@ -127,8 +161,33 @@ int main(int argc, char** argv)
             pattern::SetMicroBatching((k & 1) != 0, 0);
         }
     });
-    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    // the run, with a watch on progress: calls that stop completing are reported with the engines' state, not waited for
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(seconds);
+    uint64_t seen = 0;
+    int quiet = 0;
+    while (std::chrono::steady_clock::now() < t_end) {
+        std::this_thread::sleep_for(std::chrono::seconds(1));
+        const uint64_t now = calls.load();
+        quiet = now == seen ? quiet + 1 : 0;
+        seen = now;
+        if (quiet >= 10) {
+            std::fprintf(stderr, "no call has completed for 10 s (%llu so far)\n", (unsigned long long)now);
+            pattern::DebugDump(stderr);
+            std::_Exit(3);
+        }
+    }
     stop = true;
+    std::thread watchdog([&] {
+        for (int k = 0; k < 60; ++k) {
+            std::this_thread::sleep_for(std::chrono::seconds(1));
+            if (k == 30) {
+                std::fprintf(stderr, "threads still not joined 30 s after the stop\n");
+                pattern::DebugDump(stderr);
+                std::_Exit(4);
+            }
+        }
+    });
+    watchdog.detach();
     for (auto& th : ths) th.join();
     toggler.join();
     pattern::Shutdown();
