@@ -160,8 +160,9 @@ int oval_pattern_poll(oval_pending* pending, char* err, size_t err_cap);
  * Generate / Valid one object at a time, internal/runner/worker.go:64-200):
  * while enabled, calls arriving within window_us share one device launch. */
 void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes);
-/* Batches in flight at once (1..8, default 2) and whether a lane thread sleeps
- * on an interrupt (1) or polls (0, default) while its batch is on the device.
+/* Batches in flight at once (1..8, default 2) and whether a lane thread naps
+ * between looks at its batch's event (1: about 15 us at a time, which leaves its
+ * core to the callers) or polls (0, default) while the batch is on the device.
  * Values <= 0 / < 0 keep the current setting; applies from the next enable. */
 void oval_pattern_set_lanes(int lanes, int blocking_sync);
 /* Benchmarks only: the callers of a finished batch wake each other through a tree

@@ -162,9 +162,11 @@ hipError_t bounded_wait(const Query& query, bool sleepy)
             g_wait_timed_out = true;
             return hipErrorNotReady;
         }
-        // short waits spin; a wait that has lasted milliseconds gives the core away between looks
+        // short waits spin; a wait that has lasted milliseconds gives the core away between looks.  A sleepy
+        // waiter naps from the start, briefly (its thread's timer slack decides how briefly: the pipeline's
+        // lane threads set theirs to a microsecond).
         if (sleepy || waited > 50000000ull) {
-            const timespec nap = {0, sleepy ? 50000 : 200000};
+            const timespec nap = {0, sleepy && waited < 2000000ull ? 15000 : 200000};
             nanosleep(&nap, nullptr);
         } else if (waited > 2000000ull) {
             sched_yield();

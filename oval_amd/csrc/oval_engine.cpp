@@ -31,6 +31,14 @@
 // word once everything the batch wrote has reached host memory, and the host
 // reads its own memory.
 //
+// A caller need not wait inside the library at all: submit() reserves and writes a job like execute()
+// does and returns, try_complete() reads one word of the slot (`completed`, set by the lane to the batch's
+// sequence number) and collects the outcome once the batch is over.  Such jobs share launches with the
+// blocking callers'; a batch that holds any of them has its sleepers woken by the lane directly (a job
+// without a waiting caller cannot pass a wake-up on), a batch of nothing else wakes nobody.  A host
+// language with cheap tasks of its own (goroutines that yield between polls) thereby pays neither sleep
+// nor wake-up per call.
+//
 // One engine (everything above) per GPU of the process: a call is routed by its
 // worker ID, so a worker's objects always meet the same device, and engines share
 // nothing but the host's cores.
@@ -49,6 +57,7 @@
 #include <hip/hip_runtime.h>
 #include <linux/futex.h>
 #include <sched.h>
+#include <sys/prctl.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -694,6 +703,7 @@ void lane_loop(Pipeline* pipe)
     Pipeline& g = *pipe;
     std::unique_lock<std::mutex> lk(g.mu);
     (void)hipSetDevice(g.device);                                // a new thread starts on device 0
+    (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0ul, 0ul, 0ul);        // a lane that naps while its batch is on the device naps for microseconds, not for the default 50
     for (;;) {
         g.lane_cv.wait(lk, [&g] {
             Slot* o = g.open.load(std::memory_order_relaxed);

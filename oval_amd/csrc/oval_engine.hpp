@@ -58,9 +58,8 @@ int submit(Job& job, Ticket& t);
 bool try_complete(Ticket& t, Job& job);
 
 void set_batching(bool enable, int window_us, size_t max_bytes);
-// Lanes = batches in flight at once (1..8); blocking = lanes sleep on an
-// interrupt while their batch is on the device instead of polling.  Takes
-// effect when batching is next enabled.
+// Lanes = batches in flight at once (1..8); blocking = lanes look at their batch's event in naps of about
+// 15 us while it is on the device instead of polling it.  Takes effect when batching is next enabled.
 void set_lanes(int lanes, int blocking);
 // Shape of the tree through which the callers of a finished batch wake each other: the lane wakes
 // `roots` callers, each caller wakes `fanout` more (defaults 1 and 4; values < 1 keep the setting).

@@ -190,7 +190,7 @@ std::string LastEngineError();
 // identical either way.  A negative window keeps the current setting.
 void SetMicroBatching(bool enable, int windowMicros = 0, size_t maxBytes = 64u << 20);
 void MicroBatchingStats(uint64_t* batches, uint64_t* jobs);
-// Batches in flight at once (1..8) and whether a lane sleeps on an interrupt
+// Batches in flight at once (1..8) and whether a lane naps between looks at its event
 // (1) or polls (0) while its batch is on the device; negative / zero lanes keep
 // the current value.  Applies from the next SetMicroBatching(true).
 void SetBatchLanes(int lanes, int blockingSync);
