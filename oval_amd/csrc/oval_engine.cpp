@@ -576,6 +576,7 @@ const char* const kNoSlots = "every staging slot of this engine has been set asi
 // batching has ended) `c` is not installed.  False: `c` is still the caller's.
 bool install_open(std::unique_lock<std::mutex>& lk, Pipeline& g, Slot* c)
 {
+    c->failed = false;                                           // (callers tell "could not allocate" from "not needed" by this)
     if (!shared_ready(*c)) {
         lk.unlock();
         const int rc = ensure_slot(*c, kSharedBytes, kSharedBytes, kSharedJobs);
