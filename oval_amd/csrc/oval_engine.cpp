@@ -82,7 +82,12 @@ namespace engine {
 namespace {
 
 constexpr size_t kUnit = OVAL_UNIT_SIZE;
-constexpr size_t kSharedBytes = 16u << 20;   // body capacity of a shared slot, per direction
+// Body capacity of a shared slot, per direction.  A slot that has served shared launches keeps 2 x 16 MiB of pinned
+// and as much device memory for the life of the engine; shared use prefers slots that have them already
+// (pop_free_locked), so their number follows the batches that were ever in flight or being read out at once: a
+// handful under blocking callers, up to all 34 (2.1 GiB pinned + 2.1 GiB on the device, per engine) under hundreds of
+// two-step calls whose owners poll slowly.
+constexpr size_t kSharedBytes = 16u << 20;
 constexpr size_t kSharedJobs = 2048;         // jobs of one kind a shared slot takes
 constexpr size_t kSharedJobMax = 256u << 10;  // a bigger job runs in a slot of its own
 // A batch of at most this many body bytes, made of jobs no larger than
