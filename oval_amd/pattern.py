@@ -260,6 +260,14 @@ class PendingCall:
         _raise(self._rc, self._text)
         return self._out[:self._size].tobytes() if self._out is not None else None
 
+    def __del__(self):
+        # a call that was begun must be collected: its staging slot is held until then
+        try:
+            while self._rc is None and not self.poll():
+                pass
+        except Exception:
+            pass
+
 
 def GenerateBegin(dataSize: int, workerID: int, bucketName, obj: Object) -> PendingCall:
     b, k = _b(bucketName), _b(obj.Key)
