@@ -325,6 +325,38 @@ def rehearse_launch(args, json_fd):
         dist.destroy_process_group()
 
 
+def compat_path(seconds=2.0):
+    """The path the reference itself calls, one object per call (DecideSize ->
+    Generate -> Valid, 4-16 KiB objects; internal/runner/worker.go:77-109), timed by
+    build/compat_bench (tools/compat_bench.cpp) as a child process: 255 blocking
+    threads, and 14 threads x 32 workers with calls in two steps.  Host-bound
+    figures, reported beside the device-resident headline, never as `value`."""
+    import re
+    import subprocess
+
+    exe = os.path.join(ROOT, "build", "compat_bench")
+    if not os.path.exists(exe):
+        return {"skipped": "build/compat_bench is missing (python -c 'import __graft_entry__ as g; g.build()')"}
+    out = {}
+    for name, argv, env in (("blocking_255_threads", [str(seconds), "255", "2", "0", "1"], {}),
+                            ("two_step_14_threads_x_32_workers", [str(seconds), "14", "2", "0", "1"], {"COMPAT_ASYNC": "32"})):
+        try:
+            p = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=120, env=dict(os.environ, **env))
+            m = re.search(r"([0-9]+) put-cycles/s\s+([0-9.]+) GB/s generate\+validate\s+errors ([0-9]+)", p.stdout)
+            if p.returncode != 0 or not m:
+                out[name] = {"failed": (p.stderr or p.stdout)[-300:]}
+                continue
+            sysm = re.search(r"per put-cycle ([0-9.]+) us user \+ ([0-9.]+) us system", p.stdout)
+            out[name] = {"put_cycles_per_s": int(m.group(1)), "GBps": float(m.group(2)), "errors": int(m.group(3)),
+                         "user_us_per_put_cycle": float(sysm.group(1)) if sysm else None,
+                         "system_us_per_put_cycle": float(sysm.group(2)) if sysm else None}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"failed": str(e)}
+    out["what"] = ("one object per call through the host mirror of internal/pattern (DecideSize, Generate, Valid; 4-16 KiB), "
+                   f"{seconds:g} s each; GB/s = bytes generated + bytes validated; host-bound, not the headline")
+    return out
+
+
 class Rank:
     """What one rank process holds for the whole run."""
 
@@ -597,6 +629,8 @@ def main():
     ap.add_argument("--no-also", action="store_true",
                     help="do not run cfg3 and cfg4 after the headline workload (they are run, and reported under "
                          "`also`, when the headline is the default cfg2 without damage)")
+    ap.add_argument("--no-compat", action="store_true",
+                    help="do not time the one-object-per-call path (build/compat_bench, two child runs of 2 s) under `also`")
     ap.add_argument("--also-steps", type=int, default=10, help="timed steps of the cfg3 run under `also` (cfg4: half)")
     ap.add_argument("--sharding", default="workers", choices=["workers", "process"],
                     help="workers: one key space cut into worker ranges (default); process: rank r = process ID r")
@@ -659,6 +693,8 @@ def main():
                      "validate_GBps": round(c4["val_gbs"], 1), "counters": c4["counters"],
                      "counters_equal_plan": bool(c4["plan_ok"])},
         }
+        if world == 1 and rank == 0 and not args.no_compat:
+            also["compat_path"] = compat_path()
 
     if rank == 0:
         units, n_obj, nbytes = m["units"], m["n_obj"], m["nbytes"]

@@ -58,7 +58,13 @@ def test_single_rank_line():
         assert r["traffic"] is None and len(r["traffic_source"]) > 8, r["traffic_source"]
     # the other two single-GPU configurations under the same clock
     a = d["also"]
-    assert set(a) == {"cfg3", "cfg4"}
+    assert set(a) == {"cfg3", "cfg4", "compat_path"}
+    cp = a["compat_path"]
+    if "skipped" not in cp:
+        for k in ("blocking_255_threads", "two_step_14_threads_x_32_workers"):
+            assert cp[k]["errors"] == 0 and cp[k]["put_cycles_per_s"] > 50_000, cp[k]
+        # calls in two steps never sleep in the library: next to no system time per put-cycle
+        assert cp["two_step_14_threads_x_32_workers"]["system_us_per_put_cycle"] < 2.0
     assert a["cfg3"]["bytes_per_gpu"] == 64 * (256 << 20) and a["cfg3"]["value"] > 1000 and 0 < a["cfg3"]["frac"] < 1
     assert a["cfg3"]["fill_ms"] > 0 and a["cfg3"]["validate_ms"] > 0
     assert a["cfg4"]["counters_equal_plan"] is True and a["cfg4"]["counters"][3] > 0 and a["cfg4"]["value"] > 100
