@@ -143,7 +143,9 @@ int oval_pattern_valid_batch(size_t n, const int64_t* worker_ids, const char* co
  * blocking call would have returned (0 nil, 1 error text in err, < 0 engine
  * failure), and frees the handle.  `out` / `body` must stay valid until then
  * (Go: pinned with runtime.Pinner).  Every handle must be polled to its end: a
- * staging slot is held until its jobs have been collected.  A call that cannot
+ * staging slot is held until its jobs have been collected (oval_pattern_shutdown
+ * waits for such slots for the device time limit, at least a second, then leaves
+ * them untouched; their handles can still be polled afterwards).  A call that cannot
  * share a launch (micro-batching off, body over 256 KiB) is carried out inside
  * *_begin; its first poll returns the result. */
 #define OVAL_PATTERN_PENDING 2

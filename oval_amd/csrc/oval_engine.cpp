@@ -158,6 +158,7 @@ struct Pipeline;
 struct Slot {
     Pipeline* pipe = nullptr;             // the engine this slot belongs to
     bool quarantined = false;             // its batch never finished: the device may still write its memory
+    bool counted_out = false;             // counted in Pipeline::quarantined (mu held): set aside, or still out when shutdown() gave up on it
     bool lose_flag = false;               // test hook: the batch in flight was given a flag word nobody reads
     oval_ctx* ctx = nullptr;
     oval_layout* fill_layout = nullptr;
@@ -225,7 +226,7 @@ struct Pipeline {
     std::string err;
     int index = 0;                        // which engine of the process this is
     int quarantined = 0;                  // slots set aside for good (see Slot::quarantined)
-    uint64_t batch_ns = 20000;            // how long a shared batch has lately taken from submit to completion (lanes write, callers read)
+    std::atomic<uint64_t> batch_ns{20000};   // how long a shared batch has lately taken from submit to completion (lanes write, callers read)
     // generated bodies that still hold a slot of this engine, and its idle pinned buffers
     std::mutex parts_mu;
     std::vector<struct Parts*> live_parts;
@@ -606,7 +607,13 @@ void release_slot(Slot* s)
     {
         std::unique_lock<std::mutex> lk(g.mu);
         if (s->quarantined) {
-            g.quarantined++;                                     // never on the free list again
+            if (!s->counted_out) g.quarantined++;                // never on the free list again
+            s->counted_out = true;
+        } else if (s->counted_out) {
+            // shutdown() gave up waiting for this slot (jobs nobody had collected yet): it comes home now
+            s->counted_out = false;
+            g.quarantined--;
+            g.free_slots.push_back(s);
         } else if (!(g.enabled.load(std::memory_order_relaxed) && !g.stop && !g.open.load(std::memory_order_relaxed) &&
                      shared_ready(*s) && install_open(lk, g, s))) {
             // (callers may be waiting for an open slot because every slot was busy: a slot that is ready for
@@ -675,7 +682,8 @@ void process_batch(Slot* s, uint64_t t, bool blocking, uint64_t* phase_ns)
     else settle_slot(*s);                                        // whatever was enqueued before the failure
     const uint64_t t3 = now_ns();
     if (rc) note_failure(*s);
-    else s->pipe->batch_ns = (3 * s->pipe->batch_ns + (t3 - t1)) / 4;   // (lanes race on this estimate; any of their values will do)
+    else s->pipe->batch_ns.store((3 * s->pipe->batch_ns.load(std::memory_order_relaxed) + (t3 - t1)) / 4,
+                                 std::memory_order_relaxed);     // (two lanes may each lose the other's sample: it is an estimate)
     s->readers.store((int)n_jobs, std::memory_order_relaxed);
     // Jobs submitted without a waiting caller learn of the end from `completed`.  Nobody wakes on their
     // behalf, so they cannot be links of the wake tree: a batch that holds any of them has every sleeping
@@ -1176,7 +1184,10 @@ void execute(Job& job)
     // that sees its word change needs neither a sleep nor a wake-up through the kernel.  Then asleep on the
     // word with its lowest bit set, which tells whoever completes it that a wake-up call is needed.
     int spin_ns = g_spin_ns.load(std::memory_order_relaxed);
-    if (spin_ns < 0) spin_ns = (int)(2 * g.batch_ns < 200000 ? 2 * g.batch_ns : 200000);
+    if (spin_ns < 0) {
+        const uint64_t twice = 2 * g.batch_ns.load(std::memory_order_relaxed);
+        spin_ns = (int)(twice < 200000 ? twice : 200000);
+    }
     if (spin_ns > 0) {
         int budget = g_spin_budget.load(std::memory_order_relaxed);
         if (budget < 0) budget = direct_max() / 4;
@@ -1461,17 +1472,34 @@ void shutdown()
     for (int k = 0; k < n; ++k) {
         Pipeline& g = *g_engines[k];
         std::unique_lock<std::mutex> lk(g.mu);
-        // every slot must be home (or set aside for good) before its resources go
+        // Every slot must be home (or set aside for good) before its resources go.  A slot can stay out for
+        // ever (a call in two steps that nobody polls to its end, a generated body nobody closes): after the
+        // device time limit (at least a second) such a slot keeps what it holds and is left where it is; it
+        // rejoins the free list if its holder lets go of it later.
+        const uint64_t limit = oval_internal_device_timeout_ns();
+        const uint64_t give_up = now_ns() + (limit > 1000000000ull ? limit : 1000000000ull);
         g.slot_waiters++;
         while (g.inited && g.free_slots.size() + (size_t)g.quarantined != (size_t)kSlots) {
             lk.unlock();
             (void)reap_finished_parts(g);                        // generated bodies nobody is reading any more
             lk.lock();
             if (!g.inited || g.free_slots.size() + (size_t)g.quarantined == (size_t)kSlots) break;
+            if (now_ns() > give_up) {
+                for (Slot& s : g.slots) {
+                    bool home = s.counted_out;
+                    for (const Slot* f : g.free_slots) home |= f == &s;
+                    if (!home) {
+                        s.counted_out = true;
+                        g.quarantined++;
+                    }
+                }
+                break;
+            }
             g.slot_cv.wait_for(lk, std::chrono::milliseconds(1));
         }
         g.slot_waiters--;
-        for (Slot& s : g.slots) destroy_slot(s);
+        for (Slot& s : g.slots)
+            if (!s.counted_out) destroy_slot(s);                 // (a slot still out is in use, one set aside may still be written: both keep what they hold)
         lk.unlock();
         pool_drop_all(g);
     }

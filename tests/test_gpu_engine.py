@@ -260,3 +260,35 @@ def test_calls_in_two_steps_return_what_the_blocking_calls_return(oracle):
         bad.result()
     empty = pattern.ValidBegin(1, "b", Object("k", 0, 1), b"")
     assert empty.result() is None
+
+
+def test_shutdown_does_not_wait_for_ever_for_a_call_nobody_collected(oracle):
+    """A call in two steps holds its staging slot until it has been polled to its
+    end.  shutdown() waits for such slots for the device time limit (at least a
+    second), then leaves them as they are; the call can still be collected
+    afterwards, and its slot rejoins the others."""
+    import time
+
+    from oval_amd import pattern
+
+    pattern.set_clock(T0)
+    rng = np.random.default_rng(91)
+    items = _objects(rng, 12, oracle)
+    pattern.set_device_timeout(300)
+    pattern.set_direct_callers(0)
+    pattern.set_batching(True, window_us=100)
+    try:
+        size, wid, bucket, obj = items[0]
+        left = pattern.GenerateBegin(size, wid, bucket, obj)
+        t0 = time.monotonic()
+        pattern.shutdown()                                      # ends batching too: the job's batch is run on the way
+        took = time.monotonic() - t0
+        assert 0.9 < took < 5.0, took
+        assert left.result() == oracle.generate(size, wid, bucket, obj.Key, obj.WriteCount, T0)
+    finally:
+        pattern.set_device_timeout(30000)
+        pattern.set_direct_callers(16)
+        pattern.set_batching(False)
+        pattern.shutdown()
+        pattern.init_engines([0])
+    _check(oracle, items[1:], [_cycle(pattern, it) for it in items[1:]])
