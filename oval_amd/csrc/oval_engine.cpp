@@ -595,7 +595,7 @@ bool install_open(std::unique_lock<std::mutex>& lk, Pipeline& g, Slot* c)
     }
     reset_batch(*c);
     c->batch_seq++;
-    c->ticket.store(0, std::memory_order_relaxed);
+    c->ticket.store(0, std::memory_order_release);               // (a caller still holding this slot's address from its last time open may reserve through the ticket alone)
     g.open.store(c, std::memory_order_release);
     return true;
 }

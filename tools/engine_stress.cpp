@@ -11,15 +11,12 @@
 // body validated through a reader that delivers it in pieces; the batch forms;
 // several calls in two steps under way at once, begun and polled by one thread)
 // while another thread switches micro-batching off and on.  Exit code 0 = every
-// call gave what it had to.  (A build with -Xarch_host -fsanitize=thread links,
-// but the HIP runtime finds no device under the thread sanitizer's address-space
-// layout, so races are looked for by this run and by review, not by TSan.  The
-// address and undefined-behaviour sanitizers do work on the host side: build the
-// library's six sources with `-Xarch_host -fsanitize=address -Xarch_host
-// -fsanitize=undefined`, this file with `-fsanitize=address -fsanitize=undefined
-// -fno-gpu-sanitize`, run with ASAN_OPTIONS=detect_leaks=0; the one complaint left
-// is the sanitizer's own check inside the ROCm runtime's exit handler, after main
-// has returned.)
+// call gave what it had to.  (tools/sanitize_host.sh builds the library and this
+// file with the address and undefined-behaviour sanitizers on the host side; run
+// with ASAN_OPTIONS=detect_leaks=0.  The one complaint left is the sanitizer's own
+// check inside the ROCm runtime's exit handler, after main has returned.  Under
+// the thread sanitizer's address-space layout the HIP runtime finds no device, so
+// races are looked for by this run and by review.)
 #include <atomic>
 #include <chrono>
 #include <cstdio>
