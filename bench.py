@@ -408,6 +408,7 @@ class Rank:
         self.comm = None
         self.ranks_seen = 1
         if collective == "capi":
+            why = None
             try:
                 uid = [engine.Comm.unique_id() if self.rank == 0 else None]
                 if self.dist:
@@ -415,10 +416,21 @@ class Rank:
                 self.comm = engine.Comm(self.ctx, self.world, self.rank, uid[0])
                 self.ranks_seen = self.comm.info()[0]        # from the communicator, not from argv
             except Exception as e:  # noqa: BLE001
-                if self.world > 1 or args.collective == "capi":
-                    raise
-                # one rank has nothing to exchange: the run goes on, the line says what happened
-                collective, self.collective_note = "torch", f"capi unavailable with one rank: {e}"
+                if args.collective == "capi":
+                    raise                                    # asked for by name: no substitute
+                why = str(e)
+            if args.collective == "auto":
+                # Every rank takes the same road: if the library's communicator could not be made on any of
+                # them, all carry the sum through torch.distributed (RCCL as well) and the line says so.
+                bad = torch.tensor([1 if why else 0], dtype=torch.int32, device=torch.device("cuda", local))
+                if self.dist:
+                    self.dist.all_reduce(bad, op=self.dist.ReduceOp.MAX)
+                if int(bad.item()):
+                    if self.comm:
+                        self.comm.close()
+                        self.comm = None
+                    collective = "torch"
+                    self.collective_note = "capi unavailable, torch.distributed carries the sum: " + (why or "failed on another rank")
         if self.comm is None:
             self.ranks_seen = self.dist.get_world_size() if self.dist else 1
         self.collective = collective
