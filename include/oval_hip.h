@@ -271,7 +271,9 @@ int oval_layout_launches(const oval_layout* layout, uint32_t* fill_launches, uin
  * results_dev[n_obj]) plus, if counters_dev is not NULL, ADDS the batch totals
  * into counters_dev[OVAL_NUM_COUNTERS] (device memory, caller zeroes it).
  * Replaces the loop of Valid over validDataUnit (pattern.go:123-132,136-180).
- * Both are asynchronous on the context's stream. */
+ * Both are asynchronous on the context's stream.  The body may be any memory
+ * the GPU can address: given a buffer from oval_pinned_alloc the kernels' own
+ * stores and loads cross the link at its rate, with no staging copy. */
 int oval_fill(oval_ctx* ctx, const oval_layout* layout, void* body_dev, uint64_t body_bytes);
 int oval_validate(oval_ctx* ctx, const oval_layout* layout, const void* body_dev,
                   uint64_t body_bytes, oval_obj_result* results_dev, uint64_t* counters_dev);

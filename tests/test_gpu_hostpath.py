@@ -107,6 +107,43 @@ def test_host_calls_reuse_the_contexts_tables(ctx, oracle):
         assert np.array_equal(cnt, ecnt)
 
 
+def test_the_streaming_kernels_run_straight_on_pinned_host_memory(ctx, oracle):
+    """oval_fill / oval_validate take any pointer the GPU can address: handed a
+    pinned host buffer as the body, the kernels' own stores and loads cross the
+    link, with no staging in between.  Bytes, gaps, verdicts and counters are the
+    oracle's."""
+    import torch
+
+    from oval_amd import _lib, engine
+    from oval_amd.batch import apply_corruption_numpy, plan_corruption, span_bytes
+
+    descs = _gappy_descs(4000, 512, 1024, seed=77)
+    n = span_bytes(descs) + 512
+    p, host = _pinned(ctx, n)
+    try:
+        host[:] = 0x3C
+        layout = engine.Layout(ctx, descs)
+        _lib.check(_lib.lib().oval_fill(ctx.handle, layout._h, p, n))
+        ctx.sync()
+        exp = np.full(n, 0x3C, dtype=np.uint8)
+        oracle.fill_batch(descs.view(oracle.DESC_DTYPE), exp)
+        assert np.array_equal(host, exp)
+        apply_corruption_numpy(host, descs, plan_corruption(descs, 5e-4, seed=9))
+        results = torch.empty((len(descs), 4), dtype=torch.int32, device="cuda:0")
+        counters = torch.zeros(engine.NUM_COUNTERS, dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        _lib.check(_lib.lib().oval_validate(ctx.handle, layout._h, p, n, results.data_ptr(), counters.data_ptr()))
+        ctx.sync()
+        res = engine.results_to_numpy(results, len(descs))
+        eres, ecnt = oracle.validate_batch(descs.view(oracle.DESC_DTYPE), host)
+        for f in eres.dtype.names:
+            assert np.array_equal(res[f], eres[f]), f
+        assert np.array_equal(counters.cpu().numpy()[:len(ecnt)], ecnt) and ecnt[1] > 0
+        layout.close()
+    finally:
+        _lib.check(_lib.lib().oval_pinned_free(ctx.handle, p))
+
+
 # ---------------------------------------------------------------------------
 # Generate in parts
 # ---------------------------------------------------------------------------
