@@ -55,7 +55,8 @@ typedef enum oval_status {
     OVAL_E_LAYOUT      = -4,  /* descriptors overlap / unsorted / misaligned  */
     OVAL_E_FIELD       = -5,  /* bucket+key do not format to exactly 28 bytes */
     OVAL_E_RANGE       = -6,  /* body buffer smaller than the layout needs    */
-    OVAL_E_NODEVICE    = -7   /* no gfx950 device visible                     */
+    OVAL_E_NODEVICE    = -7,  /* no gfx950 device visible                     */
+    OVAL_E_INTERNAL    = -8   /* a C++ exception was stopped at the boundary  */
 } oval_status;
 
 /*

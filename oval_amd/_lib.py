@@ -16,6 +16,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OVAL_HIP_LIB") or os.path.join(_HERE, "liboval_hip.so")
 
 UNIT = 256
+# enum oval_status
+(OVAL_OK, OVAL_E_INVALID, OVAL_E_HIP, OVAL_E_NOMEM, OVAL_E_LAYOUT, OVAL_E_FIELD, OVAL_E_RANGE, OVAL_E_NODEVICE,
+ OVAL_E_INTERNAL) = (0, -1, -2, -3, -4, -5, -6, -7, -8)
 NO_BAD_UNIT = 0xFFFFFFFF
 NUM_COUNTERS = 12
 (CNT_OBJECTS_CHECKED, CNT_OBJECTS_BAD, CNT_UNITS_CHECKED, CNT_UNITS_BAD, CNT_BAD_BUCKET, CNT_BAD_KEY,

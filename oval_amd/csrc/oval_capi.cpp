@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <new>
@@ -120,6 +121,27 @@ int oval_internal_fail(int code, const char* fmt, ...)
     va_end(ap);
     g_err = buf;
     return code;
+}
+int oval_internal_caught(void)
+{
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        return oval_internal_fail(OVAL_E_NOMEM, "out of host memory inside the library");
+    } catch (const std::exception& e) {
+        return oval_internal_fail(OVAL_E_INTERNAL, "unexpected failure inside the library: %s", e.what());
+    } catch (...) {
+        return oval_internal_fail(OVAL_E_INTERNAL, "unexpected failure inside the library");
+    }
+}
+int oval_internal_caught_text(char* err, size_t err_cap)
+{
+    const int rc = oval_internal_caught();
+    if (err && err_cap) {
+        std::strncpy(err, g_err.c_str(), err_cap - 1);
+        err[err_cap - 1] = '\0';
+    }
+    return rc;
 }
 void oval_internal_parallel_copy(void* dst, const void* src, size_t n);   // memcpy, on several threads when large
 int oval_internal_ctx_device(const oval_ctx* ctx) { return ctx->device; }
@@ -256,23 +278,27 @@ const char* oval_last_error(void) { return g_err.c_str(); }
 const char* oval_version(void) { return "oval_hip 0.1 (gfx950)"; }
 
 int oval_set_device_timeout_ms(uint64_t ms)
-{
+try {
     g_device_timeout_ms.store(ms, std::memory_order_relaxed);
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_device_count(int* n_out)
-{
+try {
     if (!n_out) return fail(OVAL_E_INVALID, "n_out is NULL");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { *n_out = 0; return fail(OVAL_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
     *n_out = n;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_ctx_create(int device_id, void* stream, oval_ctx** out)
-{
+try {
     if (!out) return fail(OVAL_E_INVALID, "out is NULL");
     *out = nullptr;
     int n = 0;
@@ -324,10 +350,12 @@ int oval_ctx_create(int device_id, void* stream, oval_ctx** out)
     }
     *out = c;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_ctx_destroy(oval_ctx* ctx)
-{
+try {
     if (!ctx) return OVAL_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -349,13 +377,17 @@ int oval_ctx_destroy(oval_ctx* ctx)
     }
     delete ctx;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_ctx_sync(oval_ctx* ctx)
-{
+try {
     if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 }  // extern "C"
@@ -376,14 +408,16 @@ int oval_internal_ctx_sync_all(oval_ctx* ctx)
 extern "C" {
 
 int oval_ctx_stream(oval_ctx* ctx, void** stream_out)
-{
+try {
     if (!ctx || !stream_out) return fail(OVAL_E_INVALID, "NULL argument");
     *stream_out = (void*)ctx->stream;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_ctx_set_tuning(oval_ctx* ctx, int fill_threads, int validate_threads)
-{
+try {
     if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
     auto ok = [](int t) { return t <= 0 || t == 128 || t == 256 || t == 512 || t == 1024; };
     if (!ok(fill_threads) || !ok(validate_threads))
@@ -391,63 +425,77 @@ int oval_ctx_set_tuning(oval_ctx* ctx, int fill_threads, int validate_threads)
     ctx->fill_threads = fill_threads > 0 ? fill_threads : 256;
     ctx->validate_threads = validate_threads > 0 ? validate_threads : 256;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_dev_alloc(oval_ctx* ctx, size_t bytes, void** dptr_out)
-{
+try {
     if (!ctx || !dptr_out) return fail(OVAL_E_INVALID, "NULL argument");
     *dptr_out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMalloc(dptr_out, bytes ? bytes : 1));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_dev_free(oval_ctx* ctx, void* dptr)
-{
+try {
     if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
     if (!dptr) return OVAL_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipFree(dptr));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_pinned_alloc(oval_ctx* ctx, size_t bytes, void** hptr_out)
-{
+try {
     if (!ctx || !hptr_out) return fail(OVAL_E_INVALID, "NULL argument");
     *hptr_out = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipHostMalloc(hptr_out, bytes ? bytes : 1, hipHostMallocDefault));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_pinned_free(oval_ctx* ctx, void* hptr)
-{
+try {
     if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
     if (!hptr) return OVAL_OK;
     HIP_TRY(hipHostFree(hptr));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_copy_h2d(oval_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes)
-{
+try {
     if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return fail(OVAL_E_INVALID, "NULL argument");
     if (!bytes) return OVAL_OK;
     HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_copy_d2h(oval_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes)
-{
+try {
     if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return fail(OVAL_E_INVALID, "NULL argument");
     if (!bytes) return OVAL_OK;
     HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_desc_init(oval_obj_desc* d, const char* bucket, size_t bucket_len, const char* key,
                    size_t key_len, int64_t write_count, int64_t worker_id, uint64_t unix_micro,
                    uint64_t body_offset, uint32_t first_unit, uint32_t n_units)
-{
+try {
     if (!d || (!bucket && bucket_len) || (!key && key_len)) return fail(OVAL_E_INVALID, "NULL argument");
     const unsigned char* b = (const unsigned char*)bucket;
     const unsigned char* k = (const unsigned char*)key;
@@ -484,6 +532,8 @@ int oval_desc_init(oval_obj_desc* d, const char* bucket, size_t bucket_len, cons
     if (bfield != OVAL_MAX_BUCKET_LEN || kfield != OVAL_MAX_KEY_LEN) flags |= OVAL_DESC_NO_FILL;
     d->flags = flags;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 // A few helper threads for host work that is too large for one core (staging
@@ -792,13 +842,17 @@ static int layout_rebuild(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* de
 }
 
 int oval_layout_reset(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj)
-{
+try {
     return layout_rebuild(ctx, l, descs, n_obj, false);
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_layout_reset_ahead(oval_ctx* ctx, oval_layout* l, const oval_obj_desc* descs, uint64_t n_obj)
-{
+try {
     return layout_rebuild(ctx, l, descs, n_obj, true);
+} catch (...) {
+    return oval_internal_caught();
 }
 
 static_assert(sizeof(oval_obj_rec) == 12, "record must be 12 bytes");
@@ -807,7 +861,7 @@ static_assert(sizeof(oval_obj_segment) == 48 && offsetof(oval_obj_segment, key_i
 
 int oval_segment_init(oval_obj_segment* seg, const char* bucket, size_t bucket_len, int64_t worker_id,
                       uint64_t unix_micro, uint64_t key_id_base, uint32_t first_obj, uint32_t n_obj)
-{
+try {
     if (!seg) return fail(OVAL_E_INVALID, "NULL argument");
     // the same formatting and flags as a descriptor's, taken from one built for a key of the reference's shape
     oval_obj_desc d;
@@ -823,11 +877,13 @@ int oval_segment_init(oval_obj_segment* seg, const char* bucket, size_t bucket_l
     seg->bucket_len = d.bucket_len;
     seg->flags = d.flags;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_layout_reset_compact(oval_ctx* ctx, oval_layout* l, const oval_obj_segment* segs, uint64_t n_segs,
                               const oval_obj_rec* recs, uint64_t n_obj, uint32_t flags)
-{
+try {
     if (!ctx || !l || (!recs && n_obj) || (!segs && n_segs)) return fail(OVAL_E_INVALID, "NULL argument");
     if (flags & ~OVAL_RESET_AHEAD) return fail(OVAL_E_INVALID, "unknown flags 0x%x", flags);
     if (l->device != ctx->device) return fail(OVAL_E_INVALID, "layout belongs to device %d, context to %d", l->device, ctx->device);
@@ -902,10 +958,12 @@ int oval_layout_reset_compact(oval_ctx* ctx, oval_layout* l, const oval_obj_segm
                                           reinterpret_cast<unsigned long long*>(dev + recs_bytes + segs_bytes), l->descs_dev));
     }
     return layout_finish(l, sh, build_stream);
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_layout_read_descs(oval_ctx* ctx, const oval_layout* l, uint64_t first, uint64_t n, oval_obj_desc* out_host)
-{
+try {
     if (!ctx || !l || (!out_host && n)) return fail(OVAL_E_INVALID, "NULL argument");
     if (first > l->n_obj || n > l->n_obj - first)
         return fail(OVAL_E_RANGE, "descriptors [%llu, %llu) of a table of %llu", (unsigned long long)first,
@@ -915,6 +973,8 @@ int oval_layout_read_descs(oval_ctx* ctx, const oval_layout* l, uint64_t first, 
     HIP_TRY(hipMemcpy(out_host, static_cast<const oval_obj_desc*>(l->descs_dev) + first, n * sizeof(oval_obj_desc),
                       hipMemcpyDeviceToHost));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 // A pass on another stream than the one the tables were built on waits for them.
@@ -934,7 +994,7 @@ static int note_use(oval_ctx* ctx, const oval_layout* l)
 }
 
 int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, oval_layout** out)
-{
+try {
     if (!ctx || !out || (!descs && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
     *out = nullptr;
     oval_layout* l = new (std::nothrow) oval_layout;
@@ -954,10 +1014,12 @@ int oval_layout_create(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj
     }
     *out = l;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_layout_destroy(oval_ctx* ctx, oval_layout* l)
-{
+try {
     if (!l) return OVAL_OK;
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     if (l->built_ev) (void)hipEventSynchronize(l->built_ev);   // a build on the copy stream still writes the tables
@@ -970,10 +1032,12 @@ int oval_layout_destroy(oval_ctx* ctx, oval_layout* l)
     if (l->used_ev) (void)hipEventDestroy(l->used_ev);
     delete l;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_layout_launches(const oval_layout* l, uint32_t* fill_launches, uint32_t* validate_launches)
-{
+try {
     if (!l) return fail(OVAL_E_INVALID, "layout is NULL");
     const uint32_t n = l->n_tiles;
     if (fill_launches) {
@@ -983,15 +1047,19 @@ int oval_layout_launches(const oval_layout* l, uint32_t* fill_launches, uint32_t
     if (validate_launches)
         *validate_launches = n && l->n_obj ? (n + oval::kMaxTilesPerLaunch - 1) / oval::kMaxTilesPerLaunch : 0;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_layout_info(const oval_layout* l, uint64_t* n_obj, uint64_t* total_units, uint64_t* span_bytes)
-{
+try {
     if (!l) return fail(OVAL_E_INVALID, "layout is NULL");
     if (n_obj) *n_obj = l->n_obj;
     if (total_units) *total_units = l->total_units;
     if (span_bytes) *span_bytes = l->span_bytes;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 static int check_body(const oval_ctx* ctx, const oval_layout* l, const void* body, uint64_t body_bytes)
@@ -1007,7 +1075,7 @@ static int check_body(const oval_ctx* ctx, const oval_layout* l, const void* bod
 }
 
 int oval_fill(oval_ctx* ctx, const oval_layout* l, void* body_dev, uint64_t body_bytes)
-{
+try {
     int rc = check_body(ctx, l, body_dev, body_bytes);
     if (rc) return rc;
     if (l->no_fill)
@@ -1016,11 +1084,13 @@ int oval_fill(oval_ctx* ctx, const oval_layout* l, void* body_dev, uint64_t body
     if ((rc = await_tables(ctx, l))) return rc;
     HIP_TRY(oval::launch_fill(ctx->stream, cfg_of(ctx), view_of(l), body_dev, 0, tiles_of(l)));
     return note_use(ctx, l);
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_validate(oval_ctx* ctx, const oval_layout* l, const void* body_dev, uint64_t body_bytes,
                   oval_obj_result* results_dev, uint64_t* counters_dev)
-{
+try {
     int rc = check_body(ctx, l, body_dev, body_bytes);
     if (rc) return rc;
     if (!results_dev && l->n_obj) return fail(OVAL_E_INVALID, "results_dev is NULL");
@@ -1032,12 +1102,14 @@ int oval_validate(oval_ctx* ctx, const oval_layout* l, const void* body_dev, uin
     HIP_TRY(oval::launch_validate(ctx->stream, cfg_of(ctx), v, body_dev, 0, tiles_of(l), results_dev,
                                   (unsigned long long*)counters_dev, ctx->tallies_dev));
     return note_use(ctx, l);
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_validate_noalloc(oval_ctx* ctx, const oval_obj_desc* descs_dev, uint64_t n_obj, uint64_t span_bytes,
                           const void* body_dev, uint64_t body_bytes, oval_obj_result* results_dev,
                           uint64_t* counters_dev)
-{
+try {
     if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
     if (n_obj >= 0xFFFFFFF0ull) return fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
     if (span_bytes % OVAL_UNIT_SIZE) return fail(OVAL_E_INVALID, "span_bytes %llu is not a multiple of 256",
@@ -1060,16 +1132,20 @@ int oval_validate_noalloc(oval_ctx* ctx, const oval_obj_desc* descs_dev, uint64_
                                           (uint32_t)(span_bytes / OVAL_UNIT_SIZE), body_dev, results_dev,
                                           (unsigned long long*)counters_dev));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_read_unit(oval_ctx* ctx, const void* body_dev, uint64_t byte_offset, uint8_t* out256)
-{
+try {
     if (!ctx || !body_dev || !out256) return fail(OVAL_E_INVALID, "NULL argument");
     if (byte_offset % OVAL_UNIT_SIZE) return fail(OVAL_E_INVALID, "byte_offset is not a multiple of 256");
     HIP_TRY(hipMemcpyAsync(out256, (const char*)body_dev + byte_offset, OVAL_UNIT_SIZE, hipMemcpyDeviceToHost,
                            ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 }  // extern "C"
@@ -1315,14 +1391,16 @@ extern "C" {
 
 int oval_fill_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj, void* body_host,
                          uint64_t body_bytes)
-{
+try {
     return oval_internal_fill_host(ctx, descs, n_obj, body_host, body_bytes, nullptr, 0, true);
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t n_obj,
                              const void* body_host, uint64_t body_bytes, oval_obj_result* results_host,
                              uint64_t* counters_host)
-{
+try {
     if (!ctx || (!results_host && n_obj) || (!descs && n_obj)) return fail(OVAL_E_INVALID, "NULL argument");
     // Where the bodies end follows from the last descriptor (the table ascends;
     // the layout build below checks that it does).  The first slices start their
@@ -1414,6 +1492,8 @@ int oval_validate_batch_host(oval_ctx* ctx, const oval_obj_desc* descs, uint64_t
     if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? OVAL_E_NOMEM : OVAL_E_HIP, "validate_batch_host: %s", oval_internal_wait_error(e));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 }  // extern "C"
@@ -1422,7 +1502,7 @@ extern "C" {
 
 // ---- timing -----------------------------------------------------------------
 int oval_timer_create(oval_ctx* ctx, oval_timer** out)
-{
+try {
     if (!ctx || !out) return fail(OVAL_E_INVALID, "NULL argument");
     *out = nullptr;
     oval_timer* t = new (std::nothrow) oval_timer;
@@ -1433,37 +1513,47 @@ int oval_timer_create(oval_ctx* ctx, oval_timer** out)
     if (e != hipSuccess) { delete t; return fail(OVAL_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     *out = t;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_timer_destroy(oval_timer* t)
-{
+try {
     if (!t) return OVAL_OK;
     if (t->start) (void)hipEventDestroy(t->start);
     if (t->stop) (void)hipEventDestroy(t->stop);
     delete t;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_timer_start(oval_ctx* ctx, oval_timer* t)
-{
+try {
     if (!ctx || !t) return fail(OVAL_E_INVALID, "NULL argument");
     HIP_TRY(hipEventRecord(t->start, ctx->stream));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_timer_stop(oval_ctx* ctx, oval_timer* t)
-{
+try {
     if (!ctx || !t) return fail(OVAL_E_INVALID, "NULL argument");
     HIP_TRY(hipEventRecord(t->stop, ctx->stream));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_timer_elapsed_ms(oval_timer* t, float* ms_out)
-{
+try {
     if (!t || !ms_out) return fail(OVAL_E_INVALID, "NULL argument");
     HIP_TRY(hipEventSynchronize(t->stop));
     HIP_TRY(hipEventElapsedTime(ms_out, t->start, t->stop));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 }  // extern "C"

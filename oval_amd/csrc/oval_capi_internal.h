@@ -9,6 +9,12 @@
 #include "../../include/oval_hip.h"
 
 int oval_internal_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// Called inside `catch (...)` of an entry point's function-try-block: no C++ exception leaves the C ABI
+// (a host in another language could only abort on one).  Records what was caught as the thread's last
+// error and returns OVAL_E_NOMEM for std::bad_alloc, OVAL_E_INTERNAL for anything else.
+int oval_internal_caught(void);
+// The same for an entry point that hands its error text to the caller's buffer: the text goes there too.
+int oval_internal_caught_text(char* err, size_t err_cap);
 int oval_internal_ctx_device(const oval_ctx* ctx);
 hipStream_t oval_internal_ctx_stream(const oval_ctx* ctx);
 // oval_ctx_sync over the main stream and both copy streams of the context (the host-memory entry points

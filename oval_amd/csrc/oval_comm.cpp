@@ -76,7 +76,7 @@ static_assert(sizeof(ncclUniqueId) == OVAL_COMM_ID_BYTES, "the ABI carries the R
 extern "C" {
 
 int oval_comm_unique_id(uint8_t* id_out)
-{
+try {
     if (!id_out) return oval_internal_fail(OVAL_E_INVALID, "id_out is NULL");
     Rccl& r = rccl();
     if (!r.ok) return oval_internal_fail(OVAL_E_NODEVICE, "%s", r.why);
@@ -85,10 +85,12 @@ int oval_comm_unique_id(uint8_t* id_out)
     if (e != ncclSuccess) return rccl_fail("ncclGetUniqueId", e);
     std::memcpy(id_out, &id, sizeof id);
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_comm_create(oval_ctx* ctx, int n_ranks, int rank, const uint8_t* id, oval_comm** out)
-{
+try {
     if (!ctx || !id || !out) return oval_internal_fail(OVAL_E_INVALID, "NULL argument");
     *out = nullptr;
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
@@ -112,19 +114,23 @@ int oval_comm_create(oval_ctx* ctx, int n_ranks, int rank, const uint8_t* id, ov
     c->device = device;
     *out = c;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_comm_destroy(oval_comm* comm)
-{
+try {
     if (!comm) return OVAL_OK;
     (void)hipSetDevice(comm->device);
     const ncclResult_t e = rccl().CommDestroy(comm->comm);
     delete comm;
     return e == ncclSuccess ? OVAL_OK : rccl_fail("ncclCommDestroy", e);
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_comm_info(const oval_comm* comm, int* n_ranks_out, int* rank_out)
-{
+try {
     if (!comm) return oval_internal_fail(OVAL_E_INVALID, "comm is NULL");
     Rccl& r = rccl();
     int n = comm->n_ranks, me = comm->rank;
@@ -138,10 +144,12 @@ int oval_comm_info(const oval_comm* comm, int* n_ranks_out, int* rank_out)
     if (n_ranks_out) *n_ranks_out = n;
     if (rank_out) *rank_out = me;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_allreduce_counters(oval_ctx* ctx, oval_comm* comm, uint64_t* counters_dev, size_t n)
-{
+try {
     if (!ctx || !comm || (!counters_dev && n)) return oval_internal_fail(OVAL_E_INVALID, "NULL argument");
     if (((uintptr_t)counters_dev) % 8) return oval_internal_fail(OVAL_E_INVALID, "counters_dev is not 8-byte aligned");
     if (n == 0) return OVAL_OK;
@@ -151,10 +159,12 @@ int oval_allreduce_counters(oval_ctx* ctx, oval_comm* comm, uint64_t* counters_d
     const ncclResult_t e = rccl().AllReduce(counters_dev, counters_dev, n, ncclUint64, ncclSum, comm->comm,
                                             oval_internal_ctx_stream(ctx));
     return e == ncclSuccess ? OVAL_OK : rccl_fail("ncclAllReduce", e);
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_gather_first_bad(oval_ctx* ctx, const oval_obj_result* results_dev, uint64_t n_obj, uint32_t* table_dev)
-{
+try {
     if (!ctx || (n_obj && (!results_dev || !table_dev))) return oval_internal_fail(OVAL_E_INVALID, "NULL argument");
     if (n_obj >= 0xFFFFFFF0ull) return oval_internal_fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
     if (((uintptr_t)results_dev) % 16 || ((uintptr_t)table_dev) % 4)
@@ -162,10 +172,12 @@ int oval_gather_first_bad(oval_ctx* ctx, const oval_obj_result* results_dev, uin
     const hipError_t e = oval::launch_gather_first_bad(oval_internal_ctx_stream(ctx), results_dev, (uint32_t)n_obj, table_dev);
     if (e != hipSuccess) return oval_internal_fail(OVAL_E_HIP, "gather_first_bad: %s", hipGetErrorString(e));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_allreduce_first_bad(oval_ctx* ctx, oval_comm* comm, uint32_t* table_dev, size_t n)
-{
+try {
     if (!ctx || !comm || (!table_dev && n)) return oval_internal_fail(OVAL_E_INVALID, "NULL argument");
     if (((uintptr_t)table_dev) % 4) return oval_internal_fail(OVAL_E_INVALID, "table_dev is not 4-byte aligned");
     if (n == 0) return OVAL_OK;
@@ -175,6 +187,8 @@ int oval_allreduce_first_bad(oval_ctx* ctx, oval_comm* comm, uint32_t* table_dev
     const ncclResult_t e = rccl().AllReduce(table_dev, table_dev, n, ncclUint32, ncclMin, comm->comm,
                                             oval_internal_ctx_stream(ctx));
     return e == ncclSuccess ? OVAL_OK : rccl_fail("ncclAllReduce", e);
+} catch (...) {
+    return oval_internal_caught();
 }
 
 }  // extern "C"

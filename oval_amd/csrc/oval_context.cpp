@@ -1160,6 +1160,7 @@ std::pair<DescriptorTable, Error> BuildExistingDescriptors(const ExecutionContex
 // C entry points (include/oval_context.h)
 // ---------------------------------------------------------------------------
 #include "../../include/oval_context.h"
+#include "oval_capi_internal.h"
 
 struct oval_execctx {
     oval::runner::ExecutionContext ec;
@@ -1223,41 +1224,55 @@ extern "C" {
 int oval_execctx_new(const char* endpoint, const char* const* bucket_names, size_t n_buckets, int64_t num_obj,
                      int64_t num_worker, int64_t min_size, int64_t max_size, int64_t start_worker_id,
                      int64_t runner_id, oval_execctx** out, char* err, size_t err_cap)
-{
+try {
     std::vector<std::string> names;
     for (size_t i = 0; i < n_buckets; ++i) names.emplace_back(bucket_names && bucket_names[i] ? bucket_names[i] : "");
     return adopt(oval::runner::NewExecutionContext(endpoint ? endpoint : "", names, num_obj, num_worker, min_size,
                                                    max_size, start_worker_id, runner_id),
                  out, err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int oval_execctx_load(const char* json, size_t len, oval_execctx** out, char* err, size_t err_cap)
-{
+try {
     return adopt(oval::runner::LoadSavedContext(json ? json : "", json ? len : 0), out, err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int oval_execctx_load_file(const char* path, oval_execctx** out, char* err, size_t err_cap)
-{
+try {
     return adopt(oval::runner::LoadSavedContextFile(path ? path : ""), out, err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 size_t oval_execctx_marshal(const oval_execctx* ec, char* out, size_t cap)
-{
+try {
     if (!ec) return 0;
     return put_text(oval::runner::MarshalContext(ec->ec), out, cap);
+} catch (...) {
+    (void)oval_internal_caught();
+    return 0;
 }
 
 int oval_execctx_save_file(const oval_execctx* ec, const char* path, char* err, size_t err_cap)
-{
+try {
     if (!ec || !path) return OVAL_E_INVALID;
     return put_err(oval::runner::SaveContext(ec->ec, path), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
-void oval_execctx_destroy(oval_execctx* ec) { delete ec; }
+void oval_execctx_destroy(oval_execctx* ec)
+try { delete ec; } catch (...) {
+    (void)oval_internal_caught();
+}
 
 void oval_execctx_info(const oval_execctx* ec, int64_t* num_obj, int64_t* num_worker, int64_t* min_size,
                        int64_t* max_size, int64_t* start_worker_id, size_t* n_workers, size_t* n_bucket_names)
-{
+try {
     if (!ec) return;
     if (num_obj) *num_obj = ec->ec.NumObj;
     if (num_worker) *num_worker = ec->ec.NumWorker;
@@ -1266,104 +1281,167 @@ void oval_execctx_info(const oval_execctx* ec, int64_t* num_obj, int64_t* num_wo
     if (start_worker_id) *start_worker_id = ec->ec.StartWorkerID;
     if (n_workers) *n_workers = ec->ec.Workers.size();
     if (n_bucket_names) *n_bucket_names = ec->ec.BucketNames.size();
+} catch (...) {
+    (void)oval_internal_caught();
 }
 
 size_t oval_execctx_endpoint(const oval_execctx* ec, char* out, size_t cap)
-{
+try {
     return ec ? put_text(ec->ec.Endpoint, out, cap) : 0;
+} catch (...) {
+    (void)oval_internal_caught();
+    return 0;
 }
 
 int64_t oval_execctx_worker_id(const oval_execctx* ec, size_t worker)
-{
+try {
     return ec && worker < ec->ec.Workers.size() ? ec->ec.Workers[worker].id : -1;
+} catch (...) {
+    (void)oval_internal_caught();
+    return -1;
 }
 
 size_t oval_execctx_worker_buckets(const oval_execctx* ec, size_t worker)
-{
+try {
     return ec && worker < ec->ec.Workers.size() ? ec->ec.Workers[worker].BucketsWithObject.size() : 0;
+} catch (...) {
+    (void)oval_internal_caught();
+    return 0;
 }
 
 size_t oval_execctx_bucket_name(const oval_execctx* ec, size_t worker, size_t bucket, char* out, size_t cap)
-{
+try {
     if (!ec || worker >= ec->ec.Workers.size() || bucket >= ec->ec.Workers[worker].BucketsWithObject.size()) return 0;
     return put_text(ec->ec.Workers[worker].BucketsWithObject[bucket].BucketName, out, cap);
+} catch (...) {
+    (void)oval_internal_caught();
+    return 0;
 }
 
 oval_objmeta* oval_execctx_objmeta(oval_execctx* ec, size_t worker, size_t bucket)
-{
+try {
     if (!ec || worker >= ec->ec.Workers.size() || bucket >= ec->ec.Workers[worker].BucketsWithObject.size())
         return nullptr;
     return reinterpret_cast<oval_objmeta*>(&ec->ec.Workers[worker].BucketsWithObject[bucket].ObjectMeta);
+} catch (...) {
+    (void)oval_internal_caught();
+    return nullptr;
 }
 
-uint64_t oval_execctx_count_existing(const oval_execctx* ec) { return ec ? oval::runner::CountExisting(ec->ec) : 0; }
+uint64_t oval_execctx_count_existing(const oval_execctx* ec)
+try { return ec ? oval::runner::CountExisting(ec->ec) : 0; } catch (...) {
+    (void)oval_internal_caught();
+    return 0;
+}
 
 oval_objmeta* oval_objmeta_new(int64_t num_obj, int64_t key_id_offset)
-{
+try {
     return reinterpret_cast<oval_objmeta*>(new (std::nothrow) oval::object::ObjectMeta(num_obj, key_id_offset));
+} catch (...) {
+    (void)oval_internal_caught();
+    return nullptr;
 }
 
-void oval_objmeta_free(oval_objmeta* om) { delete OM(om); }
+void oval_objmeta_free(oval_objmeta* om)
+try { delete OM(om); } catch (...) {
+    (void)oval_internal_caught();
+}
 
-int64_t oval_objmeta_get_random_object(oval_objmeta* om) { return om ? index_of(OM(om), OM(om)->GetRandomObject()) : -1; }
+int64_t oval_objmeta_get_random_object(oval_objmeta* om)
+try { return om ? index_of(OM(om), OM(om)->GetRandomObject()) : -1; } catch (...) {
+    (void)oval_internal_caught();
+    return -1;
+}
 
 int oval_objmeta_register_to_existing_list(oval_objmeta* om, const char* key, size_t key_len, char* err,
                                            size_t err_cap)
-{
+try {
     if (!om) return OVAL_E_INVALID;
     return put_err(OM(om)->RegisterToExistingList(std::string(key ? key : "", key ? key_len : 0)), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int64_t oval_objmeta_pop_existing_random_object(oval_objmeta* om)
-{
+try {
     return om ? index_of(OM(om), OM(om)->PopExistingRandomObject()) : -1;
+} catch (...) {
+    (void)oval_internal_caught();
+    return -1;
 }
 
 int64_t oval_objmeta_get_existing_random_object(oval_objmeta* om)
-{
+try {
     return om ? index_of(OM(om), OM(om)->GetExistingRandomObject()) : -1;
+} catch (...) {
+    (void)oval_internal_caught();
+    return -1;
 }
 
 int oval_objmeta_exist(const oval_objmeta* om, const char* key, size_t key_len, int* exists_out, char* err,
                        size_t err_cap)
-{
+try {
     if (!om) return OVAL_E_INVALID;
     auto r = OM(om)->Exist(std::string(key ? key : "", key ? key_len : 0));
     if (exists_out) *exists_out = r.first ? 1 : 0;
     return put_err(r.second, err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 void oval_objmeta_get_head_and_tail_key(const oval_objmeta* om, char* head13, char* tail13)
-{
+try {
     if (!om) return;
     auto r = OM(om)->GetHeadAndTailKey();
     put_key13(r.first, head13);
     put_key13(r.second, tail13);
+} catch (...) {
+    (void)oval_internal_caught();
 }
 
 int oval_objmeta_tidy_up(oval_objmeta* om, char* err, size_t err_cap)
-{
+try {
     if (!om) return OVAL_E_INVALID;
     return put_err(OM(om)->TidyUp(), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
-size_t oval_objmeta_num_objects(const oval_objmeta* om) { return om ? OM(om)->ObjectList.size() : 0; }
-size_t oval_objmeta_num_existing(const oval_objmeta* om) { return om ? OM(om)->ExistingObjectIDs.size() : 0; }
+size_t oval_objmeta_num_objects(const oval_objmeta* om)
+try { return om ? OM(om)->ObjectList.size() : 0; } catch (...) {
+    (void)oval_internal_caught();
+    return 0;
+}
+size_t oval_objmeta_num_existing(const oval_objmeta* om)
+try { return om ? OM(om)->ExistingObjectIDs.size() : 0; } catch (...) {
+    (void)oval_internal_caught();
+    return 0;
+}
 
 int64_t oval_objmeta_existing_id(const oval_objmeta* om, size_t i)
-{
+try {
     return om && i < OM(om)->ExistingObjectIDs.size() ? OM(om)->ExistingObjectIDs[i] : -1;
+} catch (...) {
+    (void)oval_internal_caught();
+    return -1;
 }
 
-int64_t oval_objmeta_key_id_offset(const oval_objmeta* om) { return om ? OM(om)->KeyIDOffset : 0; }
+int64_t oval_objmeta_key_id_offset(const oval_objmeta* om)
+try { return om ? OM(om)->KeyIDOffset : 0; } catch (...) {
+    (void)oval_internal_caught();
+    return -1;
+}
 
 size_t oval_objmeta_key_prefix(const oval_objmeta* om, char* out, size_t cap)
-{
+try {
     return om ? put_text(OM(om)->KeyPrefix, out, cap) : 0;
+} catch (...) {
+    (void)oval_internal_caught();
+    return 0;
 }
 
 int oval_objmeta_get_object(const oval_objmeta* om, int64_t index, char* key13, int64_t* size, int64_t* write_count)
-{
+try {
     if (!om) return OVAL_E_INVALID;
     if (index < 0 || (uint64_t)index >= OM(om)->ObjectList.size()) return OVAL_E_RANGE;
     const oval::object::Object& o = OM(om)->ObjectList[(size_t)index];
@@ -1371,30 +1449,39 @@ int oval_objmeta_get_object(const oval_objmeta* om, int64_t index, char* key13, 
     if (size) *size = o.Size;
     if (write_count) *write_count = o.WriteCount;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_objmeta_set_object(oval_objmeta* om, int64_t index, int64_t size, int64_t write_count)
-{
+try {
     if (!om) return OVAL_E_INVALID;
     if (index < 0 || (uint64_t)index >= OM(om)->ObjectList.size()) return OVAL_E_RANGE;
     OM(om)->ObjectList[(size_t)index].Size = size;
     OM(om)->ObjectList[(size_t)index].WriteCount = write_count;
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
-void oval_object_seed_random(uint64_t seed) { oval::object::SeedRandom(seed); }
+void oval_object_seed_random(uint64_t seed)
+try { oval::object::SeedRandom(seed); } catch (...) {
+    (void)oval_internal_caught();
+}
 
 int oval_execctx_populate(oval_execctx* ec, uint64_t seed, double fraction, int64_t max_write_count, char* err,
                           size_t err_cap)
-{
+try {
     if (!ec) return OVAL_E_INVALID;
     return put_err(oval::runner::PopulateExisting(ec->ec, seed, fraction, max_write_count), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int oval_execctx_build_descs(const oval_execctx* ec, uint64_t unix_micro, size_t worker_begin, size_t worker_end,
                              oval_obj_desc* descs_out, oval_obj_ref* refs_out, uint64_t cap, uint64_t* n_out,
                              uint64_t* body_bytes_out, char* err, size_t err_cap)
-{
+try {
     if (!ec) return OVAL_E_INVALID;
     static_assert(sizeof(oval_obj_ref) == sizeof(oval::runner::ObjectRef) && offsetof(oval_obj_ref, obj_id) == 8,
                   "oval_obj_ref is ObjectRef");
@@ -1407,13 +1494,15 @@ int oval_execctx_build_descs(const oval_execctx* ec, uint64_t unix_micro, size_t
     if (n_out) *n_out = n;
     if (body_bytes_out) *body_bytes_out = bytes;
     return put_err(oval::Error::Nil(), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int oval_execctx_build_compact(const oval_execctx* ec, uint64_t unix_micro, size_t worker_begin, size_t worker_end,
                                oval_obj_segment* segs_out, uint64_t seg_cap, oval_obj_rec* recs_out, uint64_t rec_cap,
                                uint64_t* n_segs_out, uint64_t* n_obj_out, uint64_t* body_bytes_out, char* err,
                                size_t err_cap)
-{
+try {
     if (!ec) return OVAL_E_INVALID;
     size_t n_segs = 0, n_obj = 0;
     uint64_t bytes = 0;
@@ -1425,6 +1514,8 @@ int oval_execctx_build_compact(const oval_execctx* ec, uint64_t unix_micro, size
     if (n_obj_out) *n_obj_out = n_obj;
     if (body_bytes_out) *body_bytes_out = bytes;
     return put_err(oval::Error::Nil(), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 }  // extern "C"

@@ -69,6 +69,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -351,8 +352,15 @@ int ensure_slot(Slot& s, size_t up, size_t down, size_t jobs)
     // The wake words belong to shared use, not to a capacity: a slot whose arrays grew for a batch form
     // (any job count) may become the open slot later without growing again.
     if (jobs >= kSharedJobs && !s.words) {
-        s.no_waiter.reset(new uint8_t[2 * kSharedJobs]());
-        s.words.reset(new WakeWord[2 * kSharedJobs]);
+        std::unique_ptr<uint8_t[]> flags(new (std::nothrow) uint8_t[2 * kSharedJobs]());
+        std::unique_ptr<WakeWord[]> words(new (std::nothrow) WakeWord[2 * kSharedJobs]);
+        if (!flags || !words) {
+            s.err = "out of host memory for a staging slot's wake words";
+            s.failed = true;
+            return OVAL_E_NOMEM;
+        }
+        s.no_waiter = std::move(flags);
+        s.words = std::move(words);
     }
     return OVAL_OK;
 }
@@ -1379,8 +1387,14 @@ void start_lanes_locked(Pipeline& g)
     g.blocking = g_cfg.blocking;
     if (g.enabled.load()) return;
     g.stop = false;
-    g.enabled.store(true, std::memory_order_release);
-    for (int i = 0; i < g.n_lanes; ++i) g.lanes.emplace_back(lane_loop, &g);
+    // (a lane is an OS thread: the system may refuse one.  With at least one lane the engine batches; with none it
+    // stays off and calls go on launching on their own.)
+    try {
+        for (int i = 0; i < g.n_lanes; ++i) g.lanes.emplace_back(lane_loop, &g);
+    } catch (const std::exception& e) {
+        g.err = std::string("could not start a lane thread: ") + e.what();
+    }
+    if (!g.lanes.empty()) g.enabled.store(true, std::memory_order_release);
 }
 
 // g_engines_mu held.

@@ -984,6 +984,20 @@ int put_error(const oval::Error& e, char* err, size_t cap)
     return e.msg.rfind("oval engine failure: ", 0) == 0 ? OVAL_E_HIP : 1;
 }
 
+// Handler of the batch forms: every item gets the status and the text of what was caught.
+int batch_caught(size_t n, int* rcs, char* errs, size_t err_stride)
+{
+    const int rc = oval_internal_caught();
+    for (size_t i = 0; i < n && (rcs || (errs && err_stride)); ++i) {
+        if (rcs) rcs[i] = rc;
+        if (errs && err_stride) {
+            std::strncpy(errs + i * err_stride, oval_last_error(), err_stride - 1);
+            errs[i * err_stride + err_stride - 1] = '\0';
+        }
+    }
+    return rc;
+}
+
 size_t put_text(const std::string& s, char* out, size_t cap)
 {
     if (out && cap) {
@@ -1007,62 +1021,86 @@ oval::object::Object make_obj(const char* key, size_t klen, int64_t size, int64_
 
 extern "C" {
 
-int oval_pattern_init(int device_id) { return oval::pattern::Init(device_id); }
-void oval_pattern_shutdown(void) { oval::pattern::Shutdown(); }
-void oval_pattern_set_clock(int64_t unix_micro) { oval::pattern::SetClock(unix_micro); }
-void oval_pattern_seed(uint64_t seed) { oval::pattern::Seed(seed); }
+int oval_pattern_init(int device_id)
+try { return oval::pattern::Init(device_id); } catch (...) {
+    return oval_internal_caught();
+}
+void oval_pattern_shutdown(void)
+try { oval::pattern::Shutdown(); } catch (...) {
+    (void)oval_internal_caught();
+}
+void oval_pattern_set_clock(int64_t unix_micro)
+try { oval::pattern::SetClock(unix_micro); } catch (...) {
+    (void)oval_internal_caught();
+}
+void oval_pattern_seed(uint64_t seed)
+try { oval::pattern::Seed(seed); } catch (...) {
+    (void)oval_internal_caught();
+}
 
 int oval_pattern_decide_size(int64_t min_size, int64_t max_size, int64_t* size_out, char* err, size_t err_cap)
-{
+try {
     auto r = oval::pattern::DecideSize(min_size, max_size);
     if (size_out) *size_out = r.first;
     return put_error(r.second, err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int oval_pattern_decide_size_y(int64_t min_size, int64_t max_size, double y, int64_t* size_out, char* err,
                                size_t err_cap)
-{
+try {
     auto r = oval::pattern::DecideSizeFrom(min_size, max_size, y);
     if (size_out) *size_out = r.first;
     return put_error(r.second, err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int oval_pattern_generate(int64_t data_size, int64_t worker_id, const char* bucket, size_t bucket_len,
                           const char* key, size_t key_len, int64_t write_count, uint8_t* out, char* err,
                           size_t err_cap)
-{
+try {
     const oval::object::Object obj = make_obj(key, key_len, 0, write_count);
     const std::string b(bucket ? bucket : "", bucket_len);
     return put_error(oval::pattern::GenerateInto(data_size, worker_id, b, &obj, out), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int oval_pattern_generate_data_unit(int64_t unit_count, int64_t worker_id, const char* bucket,
                                     size_t bucket_len, const char* key, size_t key_len, int64_t write_count,
                                     uint8_t* out, char* err, size_t err_cap)
-{
+try {
     const oval::object::Object obj = make_obj(key, key_len, 0, write_count);
     const std::string b(bucket ? bucket : "", bucket_len);
     auto r = oval::pattern::generateDataUnit(unit_count, worker_id, b, &obj);
     if (r.second.nil() && out) std::memcpy(out, r.first.data(), r.first.size());
     return put_error(r.second, err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int oval_pattern_valid(int64_t worker_id, const char* bucket, size_t bucket_len, const char* key, size_t key_len,
                        int64_t size, int64_t write_count, const uint8_t* body, size_t body_len, char* err,
                        size_t err_cap)
-{
+try {
     const oval::object::Object obj = make_obj(key, key_len, size, write_count);
     const std::string b(bucket ? bucket : "", bucket_len);
     return put_error(oval::pattern::ValidBytes(worker_id, b, &obj, body, body_len), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int oval_pattern_valid_data_unit(int64_t unit_count, int64_t worker_id, const char* bucket, size_t bucket_len,
                                  const char* key, size_t key_len, int64_t write_count, const uint8_t* data,
                                  char* err, size_t err_cap)
-{
+try {
     const oval::object::Object obj = make_obj(key, key_len, 0, write_count);
     const std::string b(bucket ? bucket : "", bucket_len);
     return put_error(oval::pattern::validDataUnit(unit_count, worker_id, b, &obj, data), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 namespace {
@@ -1079,19 +1117,24 @@ private:
 int oval_pattern_valid_stream(int64_t worker_id, const char* bucket, size_t bucket_len, const char* key,
                               size_t key_len, int64_t size, int64_t write_count, oval_read_fn read, void* user,
                               char* err, size_t err_cap)
-{
+try {
     const oval::object::Object obj = make_obj(key, key_len, size, write_count);
     const std::string b(bucket ? bucket : "", bucket_len);
     CallbackReader rd(read, user);
     return put_error(oval::pattern::Valid(worker_id, b, &obj, rd), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
-void oval_pattern_set_stream_chunk(size_t bytes) { oval::pattern::SetStreamChunkBytes(bytes); }
+void oval_pattern_set_stream_chunk(size_t bytes)
+try { oval::pattern::SetStreamChunkBytes(bytes); } catch (...) {
+    (void)oval_internal_caught();
+}
 
 int oval_pattern_generate_parts(int64_t data_size, int64_t worker_id, const char* bucket, size_t bucket_len,
                                 const char* key, size_t key_len, int64_t write_count, int64_t part_size,
                                 oval_parts** out, char* err, size_t err_cap)
-{
+try {
     if (out) *out = nullptr;
     if (!out) return put_error(oval::Error::New("oval engine failure: out is NULL"), err, err_cap);
     const oval::object::Object obj = make_obj(key, key_len, 0, write_count);
@@ -1099,85 +1142,137 @@ int oval_pattern_generate_parts(int64_t data_size, int64_t worker_id, const char
     auto r = oval::pattern::GenerateParts(data_size, worker_id, b, &obj, part_size);
     *out = reinterpret_cast<oval_parts*>(r.first);
     return put_error(r.second, err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int64_t oval_parts_count(const oval_parts* parts)
-{
+try {
     return parts ? reinterpret_cast<const oval::pattern::GeneratedParts*>(parts)->Count() : 0;
+} catch (...) {
+    (void)oval_internal_caught();
+    return -1;
 }
 
 int oval_parts_get(oval_parts* parts, int64_t index, const uint8_t** data, size_t* len, char* err, size_t err_cap)
-{
+try {
     if (!parts || !data || !len) return put_error(oval::Error::New("oval engine failure: NULL argument"), err, err_cap);
     return put_error(reinterpret_cast<oval::pattern::GeneratedParts*>(parts)->Part(index, data, len), err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
 
 int oval_parts_release(oval_parts* parts, int64_t index)
-{
+try {
     if (!parts) return OVAL_E_INVALID;
     return reinterpret_cast<oval::pattern::GeneratedParts*>(parts)->Release(index).nil() ? 0 : OVAL_E_INVALID;
+} catch (...) {
+    return oval_internal_caught();
 }
 
-void oval_parts_close(oval_parts* parts) { delete reinterpret_cast<oval::pattern::GeneratedParts*>(parts); }
+void oval_parts_close(oval_parts* parts)
+try { delete reinterpret_cast<oval::pattern::GeneratedParts*>(parts); } catch (...) {
+    (void)oval_internal_caught();
+}
 
-void oval_parts_pool_stats(size_t* buffers, size_t* bytes) { oval::engine::parts_pool_stats(buffers, bytes); }
+void oval_parts_pool_stats(size_t* buffers, size_t* bytes)
+try { oval::engine::parts_pool_stats(buffers, bytes); } catch (...) {
+    (void)oval_internal_caught();
+}
 
 void oval_pattern_set_batching(int enable, int window_us, size_t max_bytes)
-{
+try {
     oval::pattern::SetMicroBatching(enable != 0, window_us, max_bytes);
+} catch (...) {
+    (void)oval_internal_caught();
 }
 
-void oval_pattern_set_lanes(int lanes, int blocking_sync) { oval::pattern::SetBatchLanes(lanes, blocking_sync); }
+void oval_pattern_set_lanes(int lanes, int blocking_sync)
+try { oval::pattern::SetBatchLanes(lanes, blocking_sync); } catch (...) {
+    (void)oval_internal_caught();
+}
 
-void oval_pattern_set_direct_callers(int callers) { oval::pattern::SetDirectCallers(callers); }
+void oval_pattern_set_direct_callers(int callers)
+try { oval::pattern::SetDirectCallers(callers); } catch (...) {
+    (void)oval_internal_caught();
+}
 
 int oval_pattern_generate_begin(int64_t data_size, int64_t worker_id, const char* bucket, size_t bucket_len,
                                 const char* key, size_t key_len, int64_t write_count, uint8_t* out,
                                 oval_pending** pending)
-{
+try {
     if (!pending) return oval_internal_fail(OVAL_E_INVALID, "pending is NULL");
     const oval::object::Object obj = make_obj(key, key_len, 0, write_count);
     *pending = reinterpret_cast<oval_pending*>(
         oval::pattern::GenerateBegin(data_size, worker_id, std::string(bucket ? bucket : "", bucket_len), &obj, out));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_pattern_valid_begin(int64_t worker_id, const char* bucket, size_t bucket_len, const char* key, size_t key_len,
                              int64_t size, int64_t write_count, const uint8_t* body, size_t body_len,
                              oval_pending** pending)
-{
+try {
     if (!pending) return oval_internal_fail(OVAL_E_INVALID, "pending is NULL");
     const oval::object::Object obj = make_obj(key, key_len, size, write_count);
     *pending = reinterpret_cast<oval_pending*>(
         oval::pattern::ValidBegin(worker_id, std::string(bucket ? bucket : "", bucket_len), &obj, body, body_len));
     return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
 }
 
 int oval_pattern_poll(oval_pending* pending, char* err, size_t err_cap)
-{
+try {
     if (!pending) return oval_internal_fail(OVAL_E_INVALID, "pending is NULL");
     oval::Error e = oval::Error::Nil();
     if (!oval::pattern::Poll(reinterpret_cast<oval::pattern::Pending*>(pending), &e)) return OVAL_PATTERN_PENDING;
     return put_error(e, err, err_cap);
+} catch (...) {
+    return oval_internal_caught_text(err, err_cap);
 }
-int oval_pattern_init_engines(const int* devices, int n) { return oval::pattern::InitEngines(devices, n); }
-int oval_pattern_engine_count(void) { return oval::pattern::EngineCount(); }
-void oval_pattern_set_device_timeout(uint64_t ms) { (void)oval_set_device_timeout_ms(ms); }
-void oval_pattern_set_caller_spin(int spin_ns, int max_spinners) { oval::pattern::SetCallerSpin(spin_ns, max_spinners); }
-void oval_pattern_test_lose_flags(int n) { oval::pattern::TestLoseFlags(n); }
-int oval_pattern_quarantined_slots(void) { return oval::pattern::QuarantinedSlots(); }
-void oval_pattern_set_wake_tuning(int fanout, int roots, int spin_ns) { oval::pattern::SetWakeTuning(fanout, roots, spin_ns); }
+int oval_pattern_init_engines(const int* devices, int n)
+try { return oval::pattern::InitEngines(devices, n); } catch (...) {
+    return oval_internal_caught();
+}
+int oval_pattern_engine_count(void)
+try { return oval::pattern::EngineCount(); } catch (...) {
+    return oval_internal_caught();
+}
+void oval_pattern_set_device_timeout(uint64_t ms)
+try { (void)oval_set_device_timeout_ms(ms); } catch (...) {
+    (void)oval_internal_caught();
+}
+void oval_pattern_set_caller_spin(int spin_ns, int max_spinners)
+try { oval::pattern::SetCallerSpin(spin_ns, max_spinners); } catch (...) {
+    (void)oval_internal_caught();
+}
+void oval_pattern_test_lose_flags(int n)
+try { oval::pattern::TestLoseFlags(n); } catch (...) {
+    (void)oval_internal_caught();
+}
+int oval_pattern_quarantined_slots(void)
+try { return oval::pattern::QuarantinedSlots(); } catch (...) {
+    return oval_internal_caught();
+}
+void oval_pattern_set_wake_tuning(int fanout, int roots, int spin_ns)
+try { oval::pattern::SetWakeTuning(fanout, roots, spin_ns); } catch (...) {
+    (void)oval_internal_caught();
+}
 
 void oval_pattern_batching_stats(uint64_t* batches, uint64_t* jobs)
-{
+try {
     oval::pattern::MicroBatchingStats(batches, jobs);
+} catch (...) {
+    (void)oval_internal_caught();
 }
 
 int oval_pattern_generate_batch(size_t n, const int64_t* data_sizes, const int64_t* worker_ids,
                                 const char* const* buckets, const size_t* bucket_lens, const char* const* keys,
                                 const size_t* key_lens, const int64_t* write_counts, uint8_t* const* outs,
                                 int* rcs, char* errs, size_t err_stride)
-{
+try {
     std::vector<oval::object::Object> objs(n);
     std::vector<oval::pattern::GenerateItem> items(n);
     for (size_t i = 0; i < n; ++i) {
@@ -1196,13 +1291,15 @@ int oval_pattern_generate_batch(size_t n, const int64_t* data_sizes, const int64
         if (rc < worst) worst = rc;
     }
     return worst;
+} catch (...) {
+    return batch_caught(n, rcs, errs, err_stride);
 }
 
 int oval_pattern_valid_batch(size_t n, const int64_t* worker_ids, const char* const* buckets,
                              const size_t* bucket_lens, const char* const* keys, const size_t* key_lens,
                              const int64_t* sizes, const int64_t* write_counts, const uint8_t* const* bodies,
                              const size_t* body_lens, int* rcs, char* errs, size_t err_stride)
-{
+try {
     std::vector<oval::object::Object> objs(n);
     std::vector<oval::pattern::ValidItem> items(n);
     for (size_t i = 0; i < n; ++i) {
@@ -1221,21 +1318,32 @@ int oval_pattern_valid_batch(size_t n, const int64_t* worker_ids, const char* co
         if (rc < worst) worst = rc;
     }
     return worst;
+} catch (...) {
+    return batch_caught(n, rcs, errs, err_stride);
 }
 
 size_t oval_pattern_dump(const char* text, size_t n, char* out, size_t cap)
-{
+try {
     return put_text(oval::pattern::dump(std::string(text ? text : "", n)), out, cap);
+} catch (...) {
+    (void)oval_internal_caught();
+    return 0;
 }
 
 size_t oval_pattern_hex_dump(const uint8_t* data, size_t n, char* out, size_t cap)
-{
+try {
     return put_text(oval::pattern::hexDump(data, n), out, cap);
+} catch (...) {
+    (void)oval_internal_caught();
+    return 0;
 }
 
 size_t oval_object_generate_key(int64_t obj_id, char* out, size_t cap)
-{
+try {
     return put_text(oval::object::generateKey(obj_id), out, cap);
+} catch (...) {
+    (void)oval_internal_caught();
+    return 0;
 }
 
 }  // extern "C"

@@ -180,3 +180,22 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.lower(), f"{f} mentions the oracle"
+
+
+def test_no_cpp_exception_leaves_the_c_abi():
+    """A host in another language (cgo) can only abort on a C++ exception: every
+    entry point stops them at the boundary and returns a status.  Item counts no
+    allocation can satisfy reach the library's vectors before anything else."""
+    L = _lib.lib()
+    for n, want in ((1 << 60, (_lib.OVAL_E_INTERNAL, _lib.OVAL_E_NOMEM)), (1 << 42, (_lib.OVAL_E_NOMEM, _lib.OVAL_E_INTERNAL))):
+        rc = L.oval_pattern_generate_batch(C.c_size_t(n), None, None, None, None, None, None, None, None, None, None,
+                                           C.c_size_t(0))
+        assert rc in want, rc
+        assert "inside the library" in _lib.last_error()
+    # an entry point with an error buffer of the caller's gets the text there as well
+    err, out = C.create_string_buffer(b"\xff" * 255, 256), np.zeros(4096, dtype=np.uint8)
+    rc = L.oval_pattern_generate(4096, 1, b"b", C.c_size_t(1 << 62), b"k", 1, 1, out.ctypes.data, err, 256)   # a name of 2^62 bytes
+    assert rc in (_lib.OVAL_E_INTERNAL, _lib.OVAL_E_NOMEM), rc
+    assert b"inside the library" in err.value
+    # the library is still usable afterwards
+    assert pattern.DecideSize(4096, 4096) == 4096
