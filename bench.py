@@ -93,6 +93,13 @@ def host_cpu_share():
         info["omp_num_threads"] = int(omp)
         share = min(share, int(omp))
     info["threads_used"] = max(1, share)
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return info
 
 
