@@ -136,3 +136,51 @@ def test_go_tests_use_only_what_the_binding_defines():
         for pkg in ("bytes", "io", "strings", "sync", "object", "testing"):
             if re.search(r"\b%s\.\w" % pkg, code):
                 assert any(i.rsplit("/", 1)[-1] == pkg for i in imports), f"{os.path.basename(f)} uses {pkg} without importing it"
+
+
+def _preamble(src):
+    """The C text cgo compiles for a file: the comment block right before import "C",
+    without the #cgo directives (they are for the go tool, not for the compiler)."""
+    head = src.split('import "C"', 1)[0]
+    body = head[head.rindex("/*") + 2:head.rindex("*/")]
+    return "\n".join(line for line in body.splitlines() if not line.lstrip().startswith("#cgo"))
+
+
+def test_cgo_preambles_compile_as_c_and_exports_match_their_declarations(tmp_path):
+    """What a C compiler can say about the Go files without a Go toolchain: every
+    preamble is valid C11 against include/ (cgo hands it to the C compiler as it
+    is), and the prototype cgo will generate for each //export function (Go
+    parameter types mapped to C as cgo maps them) is the one the preamble declares,
+    so the two declarations of the symbol that meet in cgo's generated C file agree."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of this image"
+    go_to_c = {"unsafe.Pointer": "void*", "*C.uint8_t": "uint8_t*", "C.size_t": "size_t", "C.int": "int",
+               "*C.char": "char*", "C.int64_t": "int64_t"}
+    for f in GO_FILES:
+        src = open(f).read()
+        pre = _preamble(src)
+        exports = re.findall(r"^//export (\w+)\nfunc (\w+)\(([^)]*)\)\s*([\w.*]*)\s*\{", src, flags=re.M)
+        checks = ""
+        for tag, name, params, ret in exports:
+            assert tag == name, f"//export {tag} sits on func {name}"
+            c_params = []
+            for p in _split_top_level(params):
+                pname, ptype = p.strip().split(None, 1)
+                c_params.append(f"{go_to_c[ptype.strip()]} {pname}")
+            proto = f"{go_to_c[ret] if ret else 'void'} {name}({', '.join(c_params)});"
+            # a second, compatible declaration is legal C; an incompatible one is an error
+            checks += f"extern {proto}\n"
+            want = re.sub(r"\s+", " ", proto)
+            assert want in re.sub(r"\s+", " ", pre), f"{os.path.basename(f)}: the preamble does not declare `{want}`"
+        if "//export" in src:
+            # cgo refuses definitions in the preamble of a file that exports
+            assert not re.search(r"\)\s*\{", pre), f"{os.path.basename(f)}: a definition in the preamble of an exporting file"
+        c = tmp_path / (os.path.basename(f) + ".c")
+        c.write_text(pre + "\n" + checks)
+        p = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                            "-I" + os.path.join(ROOT, "include"), str(c)], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+    assert any("//export" in open(f).read() for f in GO_FILES)
