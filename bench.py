@@ -241,7 +241,9 @@ def measure_traffic(argv_tail, launches):
                         continue
                     for prefix in launches:
                         if ("oval::" + prefix) in r["Kernel_Name"]:
-                            k_scale = 1.0 if (key == "read" and prefix == "fill_kernel") else scale
+                            # (the small-object fill reads 16-byte pieces of 64-byte records too, with vector loads:
+                            # 64-byte requests, tallied in full like the scalar ones)
+                            k_scale = 1.0 if (key == "read" and prefix in ("fill_kernel", "fill_small_kernel")) else scale
                             got[prefix][key] = got[prefix].get(key, 0.0) + float(r["Counter_Value"]) * 1024.0 * k_scale
                             seen += 1
             if seen == 0:
@@ -651,6 +653,9 @@ def main():
     ap.add_argument("--no-compat", action="store_true",
                     help="do not time the one-object-per-call path (build/compat_bench, two child runs of 2 s) under `also`")
     ap.add_argument("--also-steps", type=int, default=10, help="timed steps of the cfg3 run under `also` (cfg4: half)")
+    ap.add_argument("--small-object-bytes", default="",
+                    help="F or F,V: layouts that average fewer than F / V bytes per object take the small-object fill / "
+                         "validate kernel (default: the library's limits; 0: never)")
     ap.add_argument("--sharding", default="workers", choices=["workers", "process"],
                     help="workers: one key space cut into worker ranges (default); process: rank r = process ID r")
     ap.add_argument("--seed", type=int, default=1)
@@ -687,6 +692,10 @@ def main():
 
     R = Rank(args)
     rank, world = R.rank, R.world
+    if args.small_object_bytes:
+        from oval_amd import engine
+
+        engine.set_small_object_bytes(*(int(x) for x in args.small_object_bytes.split(",")))
     size_override = tuple(int(x) for x in args.sizes.split("-")) if args.sizes else None
     m = measure(R, args.workload, args.steps, args.warmup, corrupt=args.corrupt, objects=args.objects,
                 sizes=size_override, verify_plan=args.verify_plan, verify_oracle=args.verify_oracle,
@@ -722,6 +731,15 @@ def main():
         one_level = "true" if nbytes / max(n_obj, 1) < (256 << 10) else "false"
         fill_name = "fill_kernel<%d, %s>" % (args.fill_threads or 256, one_level)
         val_name = "validate_kernel<%d>" % (args.validate_threads or 256)
+        # objects of a few units take the kernels that resolve a chunk's objects at once (the library picks by the
+        # average object size of every layout; the limits are its defaults unless --small-object-bytes set them)
+        from oval_amd import engine as _engine
+        lim = [int(x) for x in args.small_object_bytes.split(",")] if args.small_object_bytes else list(_engine.SMALL_OBJECT_BYTES_DEFAULT)
+        lim = lim * 2 if len(lim) == 1 else lim
+        if m["sub_batches"] == 1 and nbytes // max(n_obj, 1) < lim[0]:
+            fill_name = "fill_small_kernel<%d>" % (args.fill_threads or 256)
+        if m["sub_batches"] == 1 and nbytes // max(n_obj, 1) < lim[1]:
+            val_name = "validate_small_kernel<%d>" % (args.validate_threads or 256)
         traffic, traffic_source = None, "none: not measured"
         if world == 1 and not args.no_traffic and not m["damaged"]:
             tail = ["--workload", args.workload, "--seed", str(args.seed), "--batch-gib", str(args.batch_gib),
@@ -730,12 +748,14 @@ def main():
             if args.sizes: tail += ["--sizes", args.sizes]
             if args.fill_threads: tail += ["--fill-threads", str(args.fill_threads)]
             if args.validate_threads: tail += ["--validate-threads", str(args.validate_threads)]
-            traffic, traffic_source = measure_traffic(tail, {"fill_kernel": m["n_fill"], "validate_kernel": m["n_val"],
+            if args.small_object_bytes: tail += ["--small-object-bytes", args.small_object_bytes]
+            fk, vk = fill_name.split("<")[0], val_name.split("<")[0]
+            traffic, traffic_source = measure_traffic(tail, {fk: m["n_fill"], vk: m["n_val"],
                                                              "warm_tables_kernel": m["n_fill"]})
         rf = kernel_roofline(fill_name, m["fill_gbs"], m["fill_ms"], m["n_fill"], units,
-                             traffic and traffic.get("fill_kernel"))
+                             traffic and traffic.get(fill_name.split("<")[0]))
         rv = kernel_roofline(val_name, m["val_gbs"], m["val_ms"], m["n_val"], units,
-                             traffic and traffic.get("validate_kernel"))
+                             traffic and traffic.get(val_name.split("<")[0]))
         if traffic and traffic.get("warm_tables_kernel"):
             rf["table_prepass_read_per_launch"] = traffic["warm_tables_kernel"].get("read", 0)
         dom = dict(rv if m["val_ms"] >= m["fill_ms"] else rf)

@@ -352,6 +352,18 @@ int oval_allreduce_first_bad(oval_ctx* ctx, oval_comm* comm, uint32_t* table_dev
  * Workgroup sizes of the fill and the validate kernel: 128, 256, 512 or 1024
  * threads; 0 restores the default (256, the fastest measured for both). */
 int oval_ctx_set_tuning(oval_ctx* ctx, int fill_threads, int validate_threads);
+/* Layouts whose objects average fewer than `fill_bytes` / `validate_bytes`
+ * (span of the batch / number of objects) are filled / validated by the kernels
+ * for objects of a few units, which resolve all objects of a 4 KiB chunk with one
+ * vector load instead of walking them one dependent scalar load at a time (the
+ * reference's smallest object is a single 256-byte unit, pattern.go:23-34).  The
+ * defaults are where the two kinds of kernel measured alike on MI355X: one-unit
+ * objects fill 2.8 x and validate 1.9 x faster with them, 4 KiB objects 10 %
+ * slower.  Process-wide, read when a layout is created or reset; 0 = never,
+ * UINT64_MAX = every layout.  Results are identical either way. */
+#define OVAL_SMALL_FILL_BYTES_DEFAULT 3072u
+#define OVAL_SMALL_VALIDATE_BYTES_DEFAULT 1280u
+int oval_set_small_object_bytes(uint64_t fill_bytes, uint64_t validate_bytes);
 
 /* ---- timing --------------------------------------------------------------
  * HIP events recorded on the context's stream, for callers (bench.py) that

@@ -84,6 +84,7 @@ SIGNATURES = {
     "oval_version": (_cp, []),
     "oval_device_count": (_int, [C.POINTER(_int)]),
     "oval_set_device_timeout_ms": (_int, [_u64]),
+    "oval_set_small_object_bytes": (_int, [_u64, _u64]),
     "oval_ctx_create": (_int, [_int, _vp, _pp]),
     "oval_ctx_destroy": (_int, [_vp]),
     "oval_ctx_sync": (_int, [_vp]),
@@ -211,6 +212,13 @@ def lib():
                 "(python -c 'import __graft_entry__ as g; g.build()'). "
                 "oval_amd has no fallback implementation."
             )
+        # A process must end up with ONE HIP runtime.  torch carries its own copy; loaded after this library
+        # (which resolves the system's), it initialises a second one and this library then finds no device.
+        # Loaded first, torch's copy serves both.  So torch goes first wherever there is a torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -69,6 +69,7 @@ struct oval_layout {
     uint32_t* chunk_first_dev = nullptr;
     void*     chunk_desc_dev = nullptr;   // per-chunk descriptor copies, only while `one_level`
     bool      one_level = false;
+    bool      small_fill = false, small_validate = false;   // objects of a few units: the kernels that resolve a chunk's objects at once
     uint64_t  n_obj = 0;
     uint64_t  total_units = 0;
     uint64_t  span_bytes = 0;
@@ -156,6 +157,8 @@ hipStream_t oval_internal_ctx_stream(const oval_ctx* ctx) { return ctx->stream; 
 // hipErrorNotReady and the thread's timed-out mark set.
 namespace {
 std::atomic<uint64_t> g_device_timeout_ms{30000};
+std::atomic<uint64_t> g_small_fill_bytes{OVAL_SMALL_FILL_BYTES_DEFAULT};          // oval_set_small_object_bytes
+std::atomic<uint64_t> g_small_validate_bytes{OVAL_SMALL_VALIDATE_BYTES_DEFAULT};
 thread_local bool g_wait_timed_out = false;
 
 uint64_t mono_ns()
@@ -238,6 +241,8 @@ oval::LayoutView view_of(const oval_layout* l)
     v.descs = l->descs_dev;
     v.chunk_first = l->chunk_first_dev;
     v.chunk_desc = l->one_level ? l->chunk_desc_dev : nullptr;
+    v.small_fill = l->small_fill;
+    v.small_validate = l->small_validate;
     v.n_obj = (uint32_t)l->n_obj;
     v.n_tiles = l->n_tiles;
     v.span_units = (uint32_t)(l->span_bytes / OVAL_UNIT_SIZE);
@@ -280,6 +285,15 @@ const char* oval_version(void) { return "oval_hip 0.1 (gfx950)"; }
 int oval_set_device_timeout_ms(uint64_t ms)
 try {
     g_device_timeout_ms.store(ms, std::memory_order_relaxed);
+    return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
+}
+
+int oval_set_small_object_bytes(uint64_t fill_bytes, uint64_t validate_bytes)
+try {
+    g_small_fill_bytes.store(fill_bytes, std::memory_order_relaxed);
+    g_small_validate_bytes.store(validate_bytes, std::memory_order_relaxed);
     return OVAL_OK;
 } catch (...) {
     return oval_internal_caught();
@@ -709,6 +723,7 @@ struct LayoutShape {
     bool no_fill = false;
     uint32_t n_tiles = 0;
     bool one_level = false;
+    bool small_fill = false, small_validate = false;
 };
 
 // First half of a rebuild: capacity (grow-only) and ordering against whatever
@@ -719,14 +734,20 @@ static int layout_prepare(oval_ctx* ctx, oval_layout* l, LayoutShape& sh, bool a
 {
     const uint64_t span_units = sh.span_bytes / OVAL_UNIT_SIZE;
     sh.n_tiles = (uint32_t)((span_units + oval::kUnitsPerTile - 1) / oval::kUnitsPerTile);
-    sh.one_level = sh.n_obj != 0 && sh.span_bytes / sh.n_obj < (256ull << 10);
+    // Objects that average under the small-object limits (gaps included) take the kernels that resolve all objects
+    // of a chunk with one vector load instead of walking them one dependent scalar load at a time; such a fill
+    // needs no per-chunk descriptor copies.
+    const uint64_t avg_bytes = sh.n_obj ? sh.span_bytes / sh.n_obj : 0;
+    sh.small_fill = sh.n_obj != 0 && avg_bytes < g_small_fill_bytes.load(std::memory_order_relaxed);
+    sh.small_validate = sh.n_obj != 0 && avg_bytes < g_small_validate_bytes.load(std::memory_order_relaxed);
+    sh.one_level = !sh.small_fill && sh.n_obj != 0 && avg_bytes < (256ull << 10);
     const uint64_t n_obj = sh.n_obj;
     const uint32_t n_tiles = sh.n_tiles;
     const bool one_level = sh.one_level;
     HIP_TRY(hipSetDevice(ctx->device));
     // Until every table is in place the layout describes nothing, so that a
     // failure below cannot leave counts that point into freed or missing tables.
-    l->n_obj = 0; l->n_tiles = 0; l->total_units = 0; l->span_bytes = 0; l->one_level = false; l->no_fill = false;
+    l->n_obj = 0; l->n_tiles = 0; l->total_units = 0; l->span_bytes = 0; l->one_level = false; l->small_fill = false; l->small_validate = false; l->no_fill = false;
     const bool grow = n_obj > l->cap_obj || !l->descs_dev || n_tiles > l->cap_tiles || !l->chunk_first_dev ||
                       (one_level && (n_tiles > l->cap_desc_tiles || !l->chunk_desc_dev)) ||
                       sh.stage_bytes > l->cap_stage_bytes || sh.compact_bytes > l->cap_compact_bytes;
@@ -807,6 +828,8 @@ static int layout_finish(oval_layout* l, const LayoutShape& sh, hipStream_t buil
     HIP_TRY(hipEventRecord(l->built_ev, build_stream));
     l->built_on = build_stream;
     l->one_level = sh.one_level;
+    l->small_fill = sh.small_fill;
+    l->small_validate = sh.small_validate;
     l->n_obj = sh.n_obj;
     l->no_fill = sh.no_fill;
     l->total_units = sh.total_units;

@@ -37,6 +37,9 @@ struct LayoutView {
     uint32_t        n_tiles;
     uint32_t        span_units;   // units from offset 0 to the end of the last object
     uint64_t        total_units;  // sum of n_units
+    // objects of a few units: the kernels that look all objects of a chunk up at once (chosen per pass:
+    // the fill gains from them up to larger objects than the validate pass does)
+    bool            small_fill, small_validate;
 };
 
 struct LaunchCfg {

@@ -533,6 +533,70 @@ __device__ __forceinline__ uint32_t w_diff(const u32x4& v, uint32_t ex, const u3
     return (v.x ^ ex) | (v.y ^ tmpl.y) | (((v.z ^ tmpl.z) | (v.w ^ tmpl.w)) & zwmask);
 }
 
+// The object walk of validate_kernel (below) as a function, for the small-object
+// kernel's wavefronts that need it: over the chunk [g0, g0 + 16) whose sixty-four
+// 16-byte pieces the wavefront holds in v, from object o0 on.  (validate_kernel
+// keeps its own copy of these lines: as a call the register allocator spills there.)
+__device__ __forceinline__ void validate_chunk_walk(sdesc_ptr descs, uint32_t n_obj, uint32_t o0, uint32_t g0,
+                                                    const u32x4 (&v)[4], oval_obj_result* __restrict__ results,
+                                                    unsigned long long* __restrict__ stripes, int lane)
+{
+    const int j = lane & 15;
+    const uint32_t grp = (uint32_t)lane >> 4;
+    const uint32_t gmul = (j == 2) ? 256u : 0u;
+    const uint32_t zwmask = (j == 2) ? 0u : 0xFFFFFFFFu;       // pattern.go:172 "Skip the unix time area."
+    const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
+                        filler_dword(4u * j + 3u)};
+    WRaw r;
+    WObj w;
+    w_fetch(descs, n_obj, o0, r);
+    const WRaw r0 = r;                                         // kept for the second walk of a bad wavefront
+    w_activate(r, n_obj, w);
+    u32x4 tmpl = w_lane_template(w, j, cpat);
+    uint32_t force = w_lane_force(w, j);
+    uint32_t anybad = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t g4 = g0 + 4u * i;
+        const uint32_t g = g4 + grp;
+        for (;;) {
+            if (g >= w.start && g < w.end) anybad |= w_diff(v[i], tmpl.x + g * gmul, tmpl, zwmask) | force;
+            if (w.end >= g4 + 4u) break;
+            w_fetch(descs, n_obj, w.o + 1u, r);
+            w_activate(r, n_obj, w);
+            tmpl = w_lane_template(w, j, cpat);
+            force = w_lane_force(w, j);
+        }
+    }
+    if (!__any(anybad != 0u)) return;
+
+    w_activate(r0, n_obj, w);
+    tmpl = w_lane_template(w, j, cpat);
+    force = w_lane_force(w, j);
+    const uint32_t slots = lane_field_slots(j);
+    WRun run = {kNone, 0, 0, kNone};
+    WTotals tot = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t g4 = g0 + 4u * i;
+        const uint32_t g = g4 + grp;
+        const u32x4 vi = v[i];
+        for (;;) {
+            const uint32_t ex = tmpl.x + g * gmul;
+            const bool bad = (g >= w.start && g < w.end) && ((w_diff(vi, ex, tmpl, zwmask) | force) != 0u);
+            if (__any(bad)) w_handle_bad(vi, ex, tmpl, w.lf, force, bad, j, slots, g4, run, tot);
+            if (w.end >= g4 + 4u) break;
+            w_flush(results, stripes, w, run, tot, g0, lane);
+            w_fetch(descs, n_obj, w.o + 1u, r);
+            w_activate(r, n_obj, w);
+            tmpl = w_lane_template(w, j, cpat);
+            force = w_lane_force(w, j);
+        }
+    }
+    if (w.o < n_obj) w_flush(results, stripes, w, run, tot, g0, lane);
+    w_totals_flush(stripes, tot, lane);
+}
+
 // Four loads per thread: a wavefront takes one whole 4 KiB chunk (wave-
 // contiguous), issues its loads, looks its object up while they are in flight,
 // then compares; only a wavefront that sees a mismatch runs the exact verdicts
@@ -608,6 +672,155 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
     if (w.o < n_obj) w_flush(results, stripes, w, run, tot, g0, lane);
     w_totals_flush(stripes, tot, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Objects of a few units (the reference's smallest object is one unit,
+// pattern.go:23-34).  The walk above meets a new object every unit or two and
+// pays a dependent scalar load for each: up to 15 in a row for a chunk of
+// one-unit objects.  Layouts whose objects average under a few KiB take these
+// kernels instead.  Objects hold at least one unit each (zero-unit objects
+// aside), so the objects that meet a chunk are among the sixteen that follow
+// its first one in the table: lane j of every 16-lane group loads the extent of
+// candidate o0 + j with ONE vector load, each group finds its unit's object by a
+// ballot over the candidates' extents, and the header lanes load their 16-byte
+// slice of that object's descriptor: two dependent vector loads however many
+// objects the chunk holds.  A wavefront whose sixteen candidates do not reach
+// the end of its units (zero-unit objects in between) takes the scalar walk.
+// ---------------------------------------------------------------------------
+struct SmallCand {
+    uint32_t start, end, lf;     // this lane's candidate: extent in units, lens and flags; start = end = kNone if none
+    bool more;                   // lane 15 of a group: objects follow the sixteenth candidate
+};
+
+__device__ __forceinline__ SmallCand small_candidates(const u32x4* __restrict__ gdescs, uint32_t n_obj, uint32_t o0, int j)
+{
+    SmallCand c;
+    const uint32_t o = o0 + (uint32_t)j;
+    const uint32_t oc = o < n_obj ? o : n_obj - 1u;            // n_obj >= 1: the load is unconditional
+    const u32x4 d3 = gdescs[4u * oc + 3u];
+    const uint32_t start = (d3.x >> 8) | (d3.y << 24);
+    c.start = o < n_obj ? start : kNone;
+    c.end = o < n_obj ? start + d3.z : kNone;
+    c.lf = d3.w;
+    c.more = o + 1u < n_obj;
+    return c;
+}
+
+// Candidate index (0-15) whose extent holds unit g of this lane's group, from the ballot of the group's
+// sixteen candidate lanes; `found` says whether there is one (a unit in a gap belongs to no object).
+__device__ __forceinline__ uint32_t small_match(const SmallCand& c, uint32_t g, uint32_t grp, bool& found)
+{
+    const unsigned long long m = __ballot(g >= c.start && g < c.end);
+    const uint32_t bits = (uint32_t)(m >> (16u * grp)) & 0xFFFFu;
+    found = bits != 0u;
+    return (uint32_t)__builtin_ctz(bits | 0x10000u);
+}
+
+// A wavefront fills one whole chunk (four stores per thread): with three dependent
+// loads in front of the first store, 4 KiB in flight per wavefront hide that
+// latency better than the 1 KiB of fill_kernel's shape.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void fill_small_kernel(sdesc_ptr descs, const u32x4* __restrict__ gdescs,
+                                                             sidx_ptr chunk_first, uint32_t n_obj,
+                                                             u32x4* __restrict__ body, uint32_t chunk_begin)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const uint32_t grp = (uint32_t)lane >> 4;
+    const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
+                        filler_dword(4u * j + 3u)};
+    const uint32_t chunk = chunk_begin + blockIdx.x * (THREADS / 64u) +
+                           __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g0 = chunk * kUnitsPerChunk;
+    const uint32_t o0 = chunk_first[chunk];
+    if (o0 >= n_obj) return;                                     // nothing ends beyond this chunk's first unit
+    u32x4* const p = body + (size_t)g0 * 16u + (uint32_t)lane;
+    const SmallCand c = small_candidates(gdescs, n_obj, o0, j);
+    // units beyond the sixteenth candidate's end may belong to objects this wavefront has not looked at
+    if (__any(j == 15 && c.more && c.end < g0 + kUnitsPerChunk)) {
+        const uint32_t gmul = (j == 2) ? 256u : 0u;
+        WRaw r;
+        WObj w;
+        w_fetch(descs, n_obj, o0, r);
+        w_activate(r, n_obj, w);
+#pragma unroll 1
+        for (uint32_t i = 0; i < 4u; ++i) {
+            const uint32_t g4 = g0 + 4u * i;
+            const uint32_t g = g4 + grp;
+            for (;;) {
+                if (g >= w.start && g < w.end) {
+                    u32x4 e = w_lane_template(w, j, cpat);
+                    e.x += g * gmul;
+                    __builtin_nontemporal_store(e, p + (size_t)i * 64u);
+                }
+                if (w.end >= g4 + 4u) break;                     // kNone for "no more objects"
+                w_fetch(descs, n_obj, w.o + 1u, r);
+                w_activate(r, n_obj, w);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t g = g0 + 4u * i + grp;
+        bool found;
+        const uint32_t idx = small_match(c, g, grp, found);
+        const uint32_t start = (uint32_t)__shfl((int)c.start, (int)(16u * grp + (idx & 15u)));
+        if (found) {
+            u32x4 e = cpat;
+            if (j < 3) e = gdescs[4u * (o0 + idx) + (uint32_t)j];
+            if (j == 2) e.x = (e.x + (g - start)) << 8;          // uint32(unitCount * 256), unitCount = first_unit + g - start
+            __builtin_nontemporal_store(e, p + (size_t)i * 64u);
+        }
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void validate_small_kernel(
+    sdesc_ptr descs, const u32x4* __restrict__ gdescs, sidx_ptr chunk_first, uint32_t n_obj, uint32_t limit_units,
+    const u32x4* __restrict__ body, uint32_t chunk_begin, oval_obj_result* __restrict__ results,
+    unsigned long long* __restrict__ stripes)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const uint32_t grp = (uint32_t)lane >> 4;
+    const uint32_t chunk = chunk_begin + blockIdx.x * (THREADS / 64u) +
+                           __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t g0 = chunk * kUnitsPerChunk;
+    const u32x4* const p = body + (size_t)g0 * 16u + (uint32_t)lane;
+    u32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = (u32x4){0u, 0u, 0u, 0u};
+        if (g0 + 4u * i + grp < limit_units) v[i] = __builtin_nontemporal_load(p + (size_t)i * 64u);
+    }
+    const uint32_t o0 = chunk_first[chunk];
+    if (o0 >= n_obj) return;                                     // no object reaches into this chunk
+    const SmallCand c = small_candidates(gdescs, n_obj, o0, j);
+    if (!__any(j == 15 && c.more && c.end < g0 + kUnitsPerChunk)) {
+        const uint32_t zwmask = (j == 2) ? 0u : 0xFFFFFFFFu;   // pattern.go:172 "Skip the unix time area."
+        const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
+                            filler_dword(4u * j + 3u)};
+        uint32_t anybad = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t g = g0 + 4u * i + grp;
+            bool found;
+            const uint32_t idx = small_match(c, g, grp, found);
+            const int src = (int)(16u * grp + (idx & 15u));
+            const uint32_t start = (uint32_t)__shfl((int)c.start, src);
+            const uint32_t lf = (uint32_t)__shfl((int)c.lf, src);
+            u32x4 t = cpat;
+            if (found && j < 3) t = gdescs[4u * (o0 + idx) + (uint32_t)j];
+            const uint32_t ex = (j == 2) ? (t.x + (g - start)) << 8 : t.x;
+            const uint32_t force = (j < 3) ? ((lf >> 16) & (1u << j)) : 0u;
+            if (found) anybad |= w_diff(v[i], ex, t, zwmask) | force;
+        }
+        if (!__any(anybad != 0u)) return;
+    }
+    // a mismatch, a descriptor that demands the exact check, or candidates that do not reach: the walk decides
+    validate_chunk_walk(descs, n_obj, o0, g0, v, results, stripes, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -924,7 +1137,10 @@ hipError_t launch_fill(hipStream_t s, const LaunchCfg& cfg, const LayoutView& lv
                                                     static_cast<const u32x4*>(lv.chunk_desc));
 #define OVAL_LAUNCH_FILL(T)                                                                                    \
     do {                                                                                                       \
-        if (cd) fill_kernel<T, true><<<n_units / (T / 16), T, 0, s>>>(sd, cf, cd, lv.n_obj, b, unit_begin);     \
+        if (lv.small_fill)                                                                                     \
+            fill_small_kernel<T><<<n_units / (T / 4), T, 0, s>>>(sd, static_cast<const u32x4*>(lv.descs), cf,   \
+                                                                 lv.n_obj, b, unit_begin / kUnitsPerChunk);    \
+        else if (cd) fill_kernel<T, true><<<n_units / (T / 16), T, 0, s>>>(sd, cf, cd, lv.n_obj, b, unit_begin); \
         else fill_kernel<T, false><<<n_units / (T / 16), T, 0, s>>>(sd, cf, cd, lv.n_obj, b, unit_begin);       \
     } while (0)
         switch (cfg.fill_threads) {
@@ -976,7 +1192,16 @@ hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView
         const uint32_t t1 = tile_end - t0 > kMaxTilesPerLaunch ? t0 + kMaxTilesPerLaunch : tile_end;
         const uint32_t chunk_begin = t0 * kChunksPerTile;
         const uint32_t n_chunks = (t1 - t0) * kChunksPerTile;
-#define OVAL_LAUNCH_VAL(T) validate_kernel<T><<<n_chunks / (T / 64), T, 0, s>>>(sd, cf, lv.n_obj, lv.span_units, b, chunk_begin, results, tallies)
+#define OVAL_LAUNCH_VAL(T)                                                                                              \
+    do {                                                                                                                \
+        if (lv.small_validate)                                                                                          \
+            validate_small_kernel<T><<<n_chunks / (T / 64), T, 0, s>>>(sd, static_cast<const u32x4*>(lv.descs), cf,      \
+                                                                       lv.n_obj, lv.span_units, b, chunk_begin, results, \
+                                                                       tallies);                                        \
+        else                                                                                                            \
+            validate_kernel<T><<<n_chunks / (T / 64), T, 0, s>>>(sd, cf, lv.n_obj, lv.span_units, b, chunk_begin,        \
+                                                                 results, tallies);                                     \
+    } while (0)
         switch (cfg.validate_threads) {
         case 128: OVAL_LAUNCH_VAL(128); break;
         case 512: OVAL_LAUNCH_VAL(512); break;
@@ -1045,6 +1270,8 @@ hipError_t launch_validate_noalloc(hipStream_t s, int device, const LaunchCfg& c
     lv.n_tiles = (span_units + kUnitsPerTile - 1u) / kUnitsPerTile;
     lv.span_units = span_units;
     lv.total_units = 0;
+    lv.small_fill = false;
+    lv.small_validate = false;
     if (lv.n_tiles > kNoAllocMaxTiles) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(tallies, 0, kTallyBytes, s);
     if (e != hipSuccess) return e;

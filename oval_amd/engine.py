@@ -20,6 +20,18 @@ def device_count() -> int:
     return n.value if rc == 0 else 0
 
 
+SMALL_OBJECT_BYTES_DEFAULT = (3072, 1280)      # OVAL_SMALL_FILL / VALIDATE_BYTES_DEFAULT of include/oval_hip.h
+
+
+def set_small_object_bytes(fill_bytes: int, validate_bytes: int | None = None) -> None:
+    """Layouts created or reset from now on whose objects average fewer than
+    `fill_bytes` / `validate_bytes` take the fill / validate kernel for objects of
+    a few units (0 = never, 2**64 - 1 = every layout; one argument sets both).  The
+    reference's smallest object is one 256-byte unit
+    (internal/pattern/pattern.go:23-34).  Results are identical either way."""
+    check(_lib.lib().oval_set_small_object_bytes(fill_bytes, fill_bytes if validate_bytes is None else validate_bytes))
+
+
 class Context:
     """One device + one stream (oval_ctx)."""
 

@@ -48,3 +48,22 @@ def golden():
         "pattern_test": json.load(open(os.path.join(d, "pattern_test.json"))),
         "short_read": json.load(open(os.path.join(d, "short_read.json"))),
     }
+
+
+def session_small_object_bytes():
+    """OVAL_TEST_SMALL_OBJECT_BYTES=N in the environment runs the whole suite with
+    the small-object kernels selected for layouts that average under N bytes per
+    object (2**64 - 1: every layout), to hold them to every parity test there is."""
+    from oval_amd import engine
+
+    v = os.environ.get("OVAL_TEST_SMALL_OBJECT_BYTES")
+    return (int(v, 0), int(v, 0)) if v else engine.SMALL_OBJECT_BYTES_DEFAULT
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _small_object_selection():
+    if os.environ.get("OVAL_TEST_SMALL_OBJECT_BYTES"):
+        from oval_amd import engine
+
+        engine.set_small_object_bytes(*session_small_object_bytes())
+    yield
