@@ -110,7 +110,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--small-object-bytes", type=lambda v: int(v, 0), default=None,
+                    help="layouts that average fewer bytes per object take the small-object kernels "
+                         "(default: the library's limits; 0xFFFFFFFFFFFFFFFF: every layout)")
     args = ap.parse_args()
+    if args.small_object_bytes is not None:
+        engine.set_small_object_bytes(args.small_object_bytes)
     oracle.build()
     ctx = engine.Context.on_torch_stream(0)
     seed_descs = build_descs("b", ["k"], [1], 1, T0, [256])
