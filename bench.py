@@ -241,9 +241,10 @@ def measure_traffic(argv_tail, launches):
                         continue
                     for prefix in launches:
                         if ("oval::" + prefix) in r["Kernel_Name"]:
-                            # (the small-object fill reads 16-byte pieces of 64-byte records too, with vector loads:
-                            # 64-byte requests, tallied in full like the scalar ones)
-                            k_scale = 1.0 if (key == "read" and prefix in ("fill_kernel", "fill_small_kernel")) else scale
+                            # (the small-object fill reads its descriptors with vector loads that run over
+                            # neighbouring records: wide requests, doubled like the others — at counter value they
+                            # would come to half the descriptor table the kernel must read)
+                            k_scale = 1.0 if (key == "read" and prefix == "fill_kernel") else scale
                             got[prefix][key] = got[prefix].get(key, 0.0) + float(r["Counter_Value"]) * 1024.0 * k_scale
                             seen += 1
             if seen == 0:
