@@ -567,6 +567,8 @@ __device__ __forceinline__ void validate_chunk_walk(sdesc_ptr descs, uint32_t n_
             tmpl = w_lane_template(w, j, cpat);
             force = w_lane_force(w, j);
         }
+        // a wavefront that has seen a mismatch walks again from the start anyway: no need to finish this walk
+        if (i < 3 && __any(anybad != 0u)) break;
     }
     if (!__any(anybad != 0u)) return;
 
@@ -644,6 +646,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
             tmpl = w_lane_template(w, j, cpat);
             force = w_lane_force(w, j);
         }
+        // a wavefront that has seen a mismatch walks again from the start anyway: no need to finish this walk
+        if (i < 3 && __any(anybad != 0u)) break;
     }
     if (!__any(anybad != 0u)) return;
 
