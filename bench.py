@@ -12,8 +12,8 @@ instead (the reference's multi-process mode).  Either way no body byte crosses
 GPUs and scaling is weak: every rank holds the same number of workers and
 objects whatever N is.  The collective is the library's own RCCL entry point
 (oval_allreduce_counters -> ncclAllReduce) under the RCCL backend.  After the
-headline workload (the default cfg2) the same invocation times cfg3 and cfg4 and
-reports them under `also`.  Prints ONE JSON line on rank 0.
+headline workload (the default cfg2) the same invocation times cfg3, cfg4 and a
+batch of the reference's smallest objects and reports them under `also`.  Prints ONE JSON line on rank 0.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python bench.py --gpus N --steps K --warmup W        (starts its own N rank processes)
@@ -722,6 +722,16 @@ def main():
                      "validate_GBps": round(c4["val_gbs"], 1), "counters": c4["counters"],
                      "counters_equal_plan": bool(c4["plan_ok"])},
         }
+        # the reference's smallest objects (one unit and up, pattern.go:23-34): the kernels that resolve all
+        # objects of a chunk at once, under the same clock (four objects for every one of the headline batch)
+        sm = measure(R, "cfg2", max(1, args.also_steps), 2, objects=4 * (args.objects or 1_000_000), sizes=(256, 1024))
+        also["small_objects"] = {
+            "workload": f"{sm['n_obj']} objects of 256-1024 bytes (DecideSize), fill+validate", "value": round(sm["value"], 2),
+            "unit": "GB/s", "steps": max(1, args.also_steps), "ms_per_step": round(sm["ms_per_step"], 4),
+            "bytes_per_gpu": sm["nbytes"], "descriptor_bytes_per_gpu": 64 * sm["n_obj"],
+            "fill_ms": round(sm["fill_ms"], 4), "validate_ms": round(sm["val_ms"], 4),
+            "fill_GBps": round(sm["fill_gbs"], 1), "validate_GBps": round(sm["val_gbs"], 1),
+            "frac": round(sm["value"] / world / HBM_PEAK_GBS, 4)}
         if world == 1 and rank == 0 and not args.no_compat:
             also["compat_path"] = compat_path()
 

@@ -58,7 +58,10 @@ def test_single_rank_line():
         assert r["traffic"] is None and len(r["traffic_source"]) > 8, r["traffic_source"]
     # the other two single-GPU configurations under the same clock
     a = d["also"]
-    assert set(a) == {"cfg3", "cfg4", "compat_path"}
+    assert set(a) == {"cfg3", "cfg4", "small_objects", "compat_path"}
+    so = a["small_objects"]
+    assert so["value"] > 100 and so["fill_ms"] > 0 and so["validate_ms"] > 0 and 0 < so["frac"] < 1
+    assert so["descriptor_bytes_per_gpu"] == 64 * 160000 and 256 * 160000 <= so["bytes_per_gpu"] <= 1024 * 160000
     cp = a["compat_path"]
     if "skipped" not in cp:
         for k in ("blocking_255_threads", "two_step_14_threads_x_32_workers"):
