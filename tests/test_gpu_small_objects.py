@@ -168,3 +168,34 @@ def test_selection_follows_the_average_object_size(gpu, oracle):
         assert np.array_equal(body.cpu().numpy(), _oracle_fill(oracle, descs, body.numel()))
         _assert_results_equal(oracle, gpu, layout, body, descs)
     layout.close()
+
+
+def test_eight_million_one_unit_objects_every_byte_and_damage(gpu, oracle):
+    """The shape the small-object kernels are for, at benchmark size: 8,000,000
+    objects of one unit (2 GB of bodies, 512 MB of descriptors), every byte against
+    the oracle on 16 host threads, then 1e-4 of the units damaged and every result
+    and counter against the oracle."""
+    from oval_amd.batch import WorkerSpace, apply_corruption_torch, plan_corruption, span_bytes, synthetic_batch
+
+    from test_gpu_fullsize import _check_corrupted_batch, _oracle_compare_fill
+
+    torch, engine, ctx = gpu["torch"], gpu["engine"], gpu["ctx"]
+    engine.set_small_object_bytes(*engine.SMALL_OBJECT_BYTES_DEFAULT)
+    descs = synthetic_batch(WorkerSpace(num_obj=8_000_000, num_worker=25, start_worker_id=0x561B), range(25),
+                            "test-bucket", 256, 256, seed=5, unix_micro=T0)
+    assert int(descs["n_units"].sum()) == len(descs) == 8_000_000
+    layout = engine.Layout(ctx, descs)
+    body = torch.empty(span_bytes(descs), dtype=torch.uint8, device="cuda:0")
+    layout.fill(body)
+    ctx.sync()
+    _oracle_compare_fill(oracle, body, descs, 100_000)
+    res, cnt = layout.validate(body)
+    ctx.sync()
+    cnt = cnt.cpu().numpy()
+    assert cnt[0] == 8_000_000 and cnt[2] == 8_000_000 and not cnt[1] and not cnt[3] and not cnt[11]
+    plan = plan_corruption(descs, 1e-4, seed=9)
+    apply_corruption_torch(body, descs, plan)
+    torch.cuda.synchronize()
+    got, cnt = _check_corrupted_batch(oracle, gpu, layout, body, descs, plan)
+    assert cnt[3] > 300
+    layout.close()
