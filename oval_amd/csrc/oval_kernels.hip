@@ -387,6 +387,11 @@ struct WTotals {
 // every wavefront of a badly corrupted batch adding to the same line, the
 // atomics serialise (measured: 70 ms instead of 1.3 ms for a cfg2 batch whose
 // every unit is bad).  fold_tallies_kernel adds the stripes up afterwards.
+// A stripe holds the eight tallies as four 64-bit words of two 32-bit counts
+// each (a batch has fewer than 2^32 units), so that a wavefront adds all of
+// them with ONE atomic instruction of four lanes:
+//   word 0: bad objects | bad units << 32       word 1: bucket | key << 32
+//   word 2: write count | offset << 32          word 3: worker ID | strict bad units << 32
 __device__ __forceinline__ unsigned long long* tally_of(unsigned long long* stripes)
 {
     return stripes + (size_t)(blockIdx.x & (kTallyStripes - 1u)) * kTallyStride;
@@ -417,7 +422,7 @@ __device__ __forceinline__ void w_flush(oval_obj_result* __restrict__ results,
                     ((unsigned long long)(r.first + w.ubias) << 32) | (unsigned long long)r.mask;
                 atomicMin(reinterpret_cast<unsigned long long*>(R), key);
                 const uint32_t old = atomicAdd(&R->bad_units, r.cnt);
-                if (old == 0u && stripes) atomicAdd(&tally_of(stripes)[OVAL_CNT_OBJECTS_BAD], 1ull);
+                if (old == 0u && stripes) atomicAdd(&tally_of(stripes)[0], 1ull);    // a bad object (word 0, low half)
             }
             atomicMin(&R->strict_first_bad_unit, r.sfirst + w.ubias);
         }
@@ -431,53 +436,51 @@ __device__ __forceinline__ void w_totals_flush(unsigned long long* __restrict__ 
                                                int lane)
 {
     if (!stripes || tot.strict == 0u) return;
-    // lanes 16 g + 0 / 1 / 2 hold disjoint slots (bucket; key, write count; offset, worker): at most 16 per slot
-    uint32_t f = 0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-        f += (uint32_t)__builtin_amdgcn_readlane((int)tot.fields, 16 * g) +
-             (uint32_t)__builtin_amdgcn_readlane((int)tot.fields, 16 * g + 1) +
-             (uint32_t)__builtin_amdgcn_readlane((int)tot.fields, 16 * g + 2);
-    if (lane == 0) {
-        unsigned long long* counters = tally_of(stripes);
-        const uint32_t bucket = f & 63u, key = (f >> 6) & 63u, wc = (f >> 12) & 63u, off = (f >> 18) & 63u, wid = (f >> 24) & 63u;
-        if (tot.objs) atomicAdd(&counters[OVAL_CNT_OBJECTS_BAD], (unsigned long long)tot.objs);
-        if (tot.units) atomicAdd(&counters[OVAL_CNT_UNITS_BAD], (unsigned long long)tot.units);
-        if (bucket) atomicAdd(&counters[OVAL_CNT_BAD_BUCKET], (unsigned long long)bucket);
-        if (key) atomicAdd(&counters[OVAL_CNT_BAD_KEY], (unsigned long long)key);
-        if (wc) atomicAdd(&counters[OVAL_CNT_BAD_WRITECNT], (unsigned long long)wc);
-        if (off) atomicAdd(&counters[OVAL_CNT_BAD_OFFSET], (unsigned long long)off);
-        if (wid) atomicAdd(&counters[OVAL_CNT_BAD_WORKER], (unsigned long long)wid);
-        atomicAdd(&counters[OVAL_CNT_STRICT_UNITS_BAD], (unsigned long long)tot.strict);
-    }
+    // The header lanes 16 g + 0 / 1 / 2 hold disjoint slots (bucket; key, write count; offset, worker): at most 16
+    // per slot over the wavefront.  Summed within each quad by two DPP steps, then over the four groups.
+    const int f0 = (lane & 15) < 3 ? (int)tot.fields : 0;
+    const int f1 = f0 + __builtin_amdgcn_update_dpp(0, f0, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+    const int f2 = f1 + __builtin_amdgcn_update_dpp(0, f1, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane(f2, 0) + (uint32_t)__builtin_amdgcn_readlane(f2, 16) +
+                       (uint32_t)__builtin_amdgcn_readlane(f2, 32) + (uint32_t)__builtin_amdgcn_readlane(f2, 48);
+    // lane k < 4 adds word k of the stripe: slots 0, 12, 24 of f are the low halves of words 1-3, slots 6 and 18
+    // the high halves of words 1 and 2
+    const uint32_t sh = 12u * (uint32_t)((lane - 1) & 3);       // (lanes 1-3: 0, 12, 24; the other lanes' values are not used)
+    const uint32_t lo = lane == 0 ? tot.objs : (f >> (sh & 31u)) & 63u;
+    const uint32_t hi = lane == 0 ? tot.units : lane == 3 ? tot.strict : (f >> ((sh + 6u) & 31u)) & 63u;
+    if (lane < 4 && (lo | hi) != 0u)
+        atomicAdd(&tally_of(stripes)[lane], (unsigned long long)lo | ((unsigned long long)hi << 32));
 }
 
-// Exact per-field outcome of one lane's 16 bytes (pattern.go:140-170); only
-// reached for a unit that failed the 128-bit compare or whose descriptor asks
-// for the exact check.  Every field is judged by one fixed lane of a unit's
+// Exact per-field outcome of one lane's 16 bytes (pattern.go:140-170) for the
+// lanes flagged `bad`: those that failed the 128-bit compare or whose descriptor
+// asks for the exact check.  Every field is judged by one fixed lane of a unit's
 // sixteen, and no lane judges more than two: the result is two bits,
 //   lane 0: A = bucket            lane 1: A = key, B = write count
 //   lane 2: A = offset, B = worker ID        lanes 3-15: A = filler
 // The numeric fields are compares of the XOR of the lane's bytes with its
-// template; the one divergent branch is the TrimSpace compare of a name field,
-// taken only by a name lane whose bytes differ from the formatted expected name
-// (or whose expected name has white space at an edge, `force`): a stale
-// generation, where only the write count differs, never takes it.
+// template, selected by the lane's place without a branch; the TrimSpace compare
+// of a name field sits behind a wave-uniform branch that is taken only when some
+// flagged name lane's bytes differ from the formatted expected name (or its
+// expected name has white space at an edge, `force`): a stale generation, where
+// only the write count differs, never takes it.  Called by all 64 lanes.
 __device__ __forceinline__ uint32_t lane_verdicts(const u32x4& v, uint32_t ex, const u32x4& tmpl, uint32_t lf,
-                                                  uint32_t force, int j)
+                                                  uint32_t force, bool bad, int j)
 {
     const uint32_t dx = v.x ^ ex, dy = v.y ^ tmpl.y, dz = v.z ^ tmpl.z, dw = v.w ^ tmpl.w;
-    if (j >= 3) return 1u;                                       // a filler lane is only here because its bytes differ
-    if (j == 2) return (dx != 0u ? 1u : 0u) | ((dy | force) != 0u ? 2u : 0u);    // force: worker ID outside uint32
-    uint32_t ab = (j == 1 && dw != 0u) ? 2u : 0u;
-    const uint32_t name_diff = dx | dy | dz | (j == 0 ? dw : 0u);    // bucket: 16 bytes, key: the first 12
-    if ((name_diff | force) != 0u) {
-        const int width = j == 0 ? 16 : 12;
-        const int len = (int)((j == 0 ? lf : lf >> 8) & 0xFFu);
-        if (!trimmed_equals([&](int i) { return reg_byte(v, i); }, width, [&](int i) { return reg_byte(tmpl, i); }, len))
-            ab |= 1u;
+    uint32_t a = (j >= 3) ? 1u : (j == 2 && dx != 0u) ? 1u : 0u;       // a flagged filler lane is flagged because its bytes differ
+    const uint32_t b = (j == 2) ? ((dy | force) != 0u ? 2u : 0u)       // force: worker ID outside uint32
+                                : (j == 1 && dw != 0u) ? 2u : 0u;
+    const bool name = bad && j < 2 && (dx | dy | dz | (j == 0 ? dw : 0u) | force) != 0u;   // bucket: 16 bytes, key: the first 12
+    if (__any(name)) {
+        if (name) {
+            const int width = j == 0 ? 16 : 12;
+            const int len = (int)((j == 0 ? lf : lf >> 8) & 0xFFu);
+            if (!trimmed_equals([&](int i) { return reg_byte(v, i); }, width, [&](int i) { return reg_byte(tmpl, i); }, len))
+                a = 1u;
+        }
     }
-    return ab;
+    return bad ? (a | b) : 0u;
 }
 
 // Where a lane's two verdicts are counted in WTotals::fields (see there): shift of A | shift of B << 8.
@@ -490,33 +493,32 @@ __device__ __forceinline__ uint32_t lane_field_slots(int j)
 // units, the flagged ones all inside object w).  Two ballots put the verdicts of
 // all four units into scalar registers, A and B of lane l of unit u at bit
 // 16 u + l; shifted down to bit 16 u the five reference fields combine with
-// scalar ANDs and ORs: no cross-lane traffic.  (Six ballots, one per field, cost
-// a batch whose every unit is bad 5 % more; counting the fields with scalar
-// population counts of the ballots instead of in a vector register cost 3 %.)
+// scalar ORs: no cross-lane traffic.  The field mask of a unit is picked out of
+// the ballots only for the first bad unit of an object.  (Six ballots, one per
+// field, cost a batch whose every unit is bad 5 % more; counting the fields with
+// scalar population counts of the ballots instead of in a vector register cost 3 %.)
 __device__ __forceinline__ void w_handle_bad(const u32x4& v, uint32_t ex, const u32x4& tmpl, uint32_t lf,
                                              uint32_t force, bool bad, int j, uint32_t slots, uint32_t g4, WRun& r,
                                              WTotals& t)
 {
-    const uint32_t ab = bad ? lane_verdicts(v, ex, tmpl, lf, force, j) : 0u;
+    const uint32_t ab = lane_verdicts(v, ex, tmpl, lf, force, bad, j);
     const unsigned long long A = __ballot((ab & 1u) != 0u), B = __ballot((ab & 2u) != 0u);
-    constexpr unsigned long long m0 = 0x0001000100010001ull;
-    const unsigned long long bb = A & m0, bk = (A >> 1) & m0, bo = (A >> 2) & m0;
-    const unsigned long long bw = (B >> 1) & m0, bi = (B >> 2) & m0;
-    const unsigned long long bf = A & 0xFFF8FFF8FFF8FFF8ull;
-    const unsigned long long refu = bb | bk | bw | bo | bi;    // bit 16 u: unit u has a reference-visible mismatch
-    // bit 16 u + 15 of `fu`: some filler lane of unit u is set (a carry out of the low 15 bits, or bit 15 itself)
-    unsigned long long fu = ((bf & 0x7FFF7FFF7FFF7FFFull) + 0x7FFF7FFF7FFF7FFFull) | bf;
-    fu = (fu >> 15) & m0;
-    const unsigned long long anyu = refu | fu;
+    constexpr unsigned long long m0 = 0x0001000100010001ull, low15 = 0x7FFF7FFF7FFF7FFFull;
+    // bit 16 u: unit u has a reference-visible mismatch (A of lanes 0-2, B of lanes 1-2)
+    const unsigned long long refu = (A | (A >> 1) | (A >> 2) | (B >> 1) | (B >> 2)) & m0;
+    // bit 16 u: some lane of unit u is set at all, filler included (a carry out of the group's low 15 bits, or bit 15 itself)
+    const unsigned long long X = A | B;
+    const unsigned long long anyu = ((((X & low15) + low15) | X) >> 15) & m0;
     // this lane's own verdicts, each in its field's slot
     t.fields += ((ab & 1u) << (slots & 31u)) + ((ab >> 1) << (slots >> 8));
     if (refu) {
         const uint32_t sh = (uint32_t)__builtin_ctzll(refu);    // 16 x the lowest bad unit
         if (r.cnt == 0u) {                                      // units arrive in ascending order
             r.first = g4 + (sh >> 4);
-            r.mask = (uint32_t)((bb >> sh) & 1ull) * OVAL_BAD_BUCKET | (uint32_t)((bk >> sh) & 1ull) * OVAL_BAD_KEY |
-                     (uint32_t)((bw >> sh) & 1ull) * OVAL_BAD_WRITECNT | (uint32_t)((bo >> sh) & 1ull) * OVAL_BAD_OFFSET |
-                     (uint32_t)((bi >> sh) & 1ull) * OVAL_BAD_WORKER;
+            const uint32_t a3 = (uint32_t)(A >> sh) & 7u, b3 = (uint32_t)(B >> sh) & 6u;   // bucket, key, offset | write count, worker
+            static_assert(OVAL_BAD_BUCKET == 1u && OVAL_BAD_KEY == 2u && OVAL_BAD_WRITECNT == 4u && OVAL_BAD_OFFSET == 8u &&
+                              OVAL_BAD_WORKER == 16u, "the field mask is assembled by shifts");
+            r.mask = (a3 & 3u) | ((b3 & 2u) << 1) | ((a3 & 4u) << 1) | ((b3 & 4u) << 2);
         }
         const uint32_t n = (uint32_t)__builtin_popcountll(refu);
         r.cnt += n;
@@ -990,11 +992,15 @@ __global__ __launch_bounds__(256) void fold_tallies_kernel(unsigned long long* _
     if (threadIdx.x < OVAL_NUM_COUNTERS) sum[threadIdx.x] = 0ull;
     __syncthreads();
     unsigned long long* mine = stripes + (size_t)threadIdx.x * kTallyStride;
-    for (int c = 0; c < OVAL_NUM_COUNTERS; ++c) {
-        const unsigned long long x = mine[c];
+    // which counters the two halves of a stripe's four words are (see tally_of)
+    const int lo_of[4] = {OVAL_CNT_OBJECTS_BAD, OVAL_CNT_BAD_BUCKET, OVAL_CNT_BAD_WRITECNT, OVAL_CNT_BAD_WORKER};
+    const int hi_of[4] = {OVAL_CNT_UNITS_BAD, OVAL_CNT_BAD_KEY, OVAL_CNT_BAD_OFFSET, OVAL_CNT_STRICT_UNITS_BAD};
+    for (int w = 0; w < 4; ++w) {
+        const unsigned long long x = mine[w];
         if (x) {
-            atomicAdd(&sum[c], x);
-            mine[c] = 0ull;
+            if (x & 0xFFFFFFFFull) atomicAdd(&sum[lo_of[w]], x & 0xFFFFFFFFull);
+            if (x >> 32) atomicAdd(&sum[hi_of[w]], x >> 32);
+            mine[w] = 0ull;
         }
     }
     __syncthreads();
