@@ -178,7 +178,8 @@ int oval_desc_init(oval_obj_desc* d,
  * Uploads `n_obj` descriptors and builds the device-side chunk index.
  * Requirements (checked; OVAL_E_LAYOUT otherwise): body_offset is a multiple
  * of 256 and bodies are in ascending, non-overlapping order (gaps and
- * zero-unit objects are allowed).  The layout can be used for any number of
+ * zero-unit objects are allowed); at most 2^30 objects and just under 1 TiB of
+ * bodies per batch.  The layout can be used for any number of
  * fill / validate passes and owns all device memory it needs, so those passes
  * allocate nothing.  The descriptor array is copied before the call returns;
  * the upload and the index build run asynchronously on the context's stream,

@@ -98,6 +98,9 @@ struct oval_timer {
 
 namespace {
 
+// The kernels index the descriptor table in 16-byte quarters with 32-bit arithmetic (4 * object + quarter).
+constexpr uint64_t kMaxObjects = 1ull << 30;
+
 thread_local std::string g_err;
 
 int fail(int code, const char* fmt, ...)
@@ -692,7 +695,7 @@ static int scan_range(const oval_obj_desc* descs, ScanPart* part)
 static int scan_descs(const oval_obj_desc* descs, uint64_t n_obj, uint64_t* total_units_out,
                       uint64_t* span_bytes_out, bool* no_fill_out, std::vector<uint64_t>* fix)
 {
-    if (n_obj >= 0xFFFFFFF0ull) return fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
+    if (n_obj > kMaxObjects) return fail(OVAL_E_LAYOUT, "too many objects (%llu): a batch holds at most 2^30", (unsigned long long)n_obj);
     const uint64_t n_parts = n_obj >= (128u << 10) ? (n_obj >> 16 < 8 ? n_obj >> 16 : 8) : 1;
     std::vector<ScanPart> parts(n_parts);
     for (uint64_t p = 0; p < n_parts; ++p) {
@@ -910,7 +913,7 @@ try {
     if (!ctx || !l || (!recs && n_obj) || (!segs && n_segs)) return fail(OVAL_E_INVALID, "NULL argument");
     if (flags & ~OVAL_RESET_AHEAD) return fail(OVAL_E_INVALID, "unknown flags 0x%x", flags);
     if (l->device != ctx->device) return fail(OVAL_E_INVALID, "layout belongs to device %d, context to %d", l->device, ctx->device);
-    if (n_obj >= 0xFFFFFFF0ull) return fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
+    if (n_obj > kMaxObjects) return fail(OVAL_E_LAYOUT, "too many objects (%llu): a batch holds at most 2^30", (unsigned long long)n_obj);
     if (n_segs > n_obj) return fail(OVAL_E_LAYOUT, "%llu segments for %llu objects: a segment holds at least one",
                                     (unsigned long long)n_segs, (unsigned long long)n_obj);
     LayoutShape sh;
@@ -1134,7 +1137,7 @@ int oval_validate_noalloc(oval_ctx* ctx, const oval_obj_desc* descs_dev, uint64_
                           uint64_t* counters_dev)
 try {
     if (!ctx) return fail(OVAL_E_INVALID, "ctx is NULL");
-    if (n_obj >= 0xFFFFFFF0ull) return fail(OVAL_E_LAYOUT, "too many objects (%llu)", (unsigned long long)n_obj);
+    if (n_obj > kMaxObjects) return fail(OVAL_E_LAYOUT, "too many objects (%llu): a batch holds at most 2^30", (unsigned long long)n_obj);
     if (span_bytes % OVAL_UNIT_SIZE) return fail(OVAL_E_INVALID, "span_bytes %llu is not a multiple of 256",
                                                  (unsigned long long)span_bytes);
     if (span_bytes > OVAL_NOALLOC_MAX_SPAN)
