@@ -199,3 +199,30 @@ def test_eight_million_one_unit_objects_every_byte_and_damage(gpu, oracle):
     got, cnt = _check_corrupted_batch(oracle, gpu, layout, body, descs, plan)
     assert cnt[3] > 300
     layout.close()
+
+
+def test_small_objects_through_the_host_memory_entry_points(gpu, oracle):
+    """Bodies that start and end in host memory (oval_fill_batch_host /
+    oval_validate_batch_host, 32 MiB slices through the device): 400,000 objects of
+    one to three units, i.e. several slices of the small-object kernels, with gaps;
+    bytes outside the objects are left alone."""
+    from oval_amd.batch import span_bytes
+
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    engine.set_small_object_bytes(*engine.SMALL_OBJECT_BYTES_DEFAULT)
+    rng = np.random.default_rng(23)
+    units = rng.integers(1, 4, size=400_000)
+    descs = _table(rng, units, gap=256)
+    n = span_bytes(descs)
+    assert n > 3 * (32 << 20)
+    body = np.full(n, 0xEE, dtype=np.uint8)
+    ctx.fill_batch_host(descs, body)
+    exp = np.full(n, 0xEE, dtype=np.uint8)
+    oracle.fill_batch(descs.view(oracle.DESC_DTYPE), exp)
+    assert np.array_equal(body, exp)
+    _damage(rng, body, exp, descs, units, rounds=200)
+    res, cnt = ctx.validate_batch_host(descs, body)
+    eres, ecnt = oracle.validate_batch(descs.view(oracle.DESC_DTYPE), body)
+    for f in eres.dtype.names:
+        assert np.array_equal(res[f], eres[f]), f
+    assert np.array_equal(cnt, ecnt) and ecnt[3] > 50
