@@ -657,6 +657,9 @@ def main():
     ap.add_argument("--small-object-bytes", default="",
                     help="F or F,V: layouts that average fewer than F / V bytes per object take the small-object fill / "
                          "validate kernel (default: the library's limits; 0: never)")
+    ap.add_argument("--big-object-bytes", type=int, default=-1,
+                    help="layouts that average at least this many bytes per object take the validate kernel for "
+                         "multipart-sized bodies (default: the library's limit; 0: every layout)")
     ap.add_argument("--sharding", default="workers", choices=["workers", "process"],
                     help="workers: one key space cut into worker ranges (default); process: rank r = process ID r")
     ap.add_argument("--seed", type=int, default=1)
@@ -697,6 +700,10 @@ def main():
         from oval_amd import engine
 
         engine.set_small_object_bytes(*(int(x) for x in args.small_object_bytes.split(",")))
+    if args.big_object_bytes >= 0:
+        from oval_amd import engine
+
+        engine.set_big_object_bytes(args.big_object_bytes)
     size_override = tuple(int(x) for x in args.sizes.split("-")) if args.sizes else None
     m = measure(R, args.workload, args.steps, args.warmup, corrupt=args.corrupt, objects=args.objects,
                 sizes=size_override, verify_plan=args.verify_plan, verify_oracle=args.verify_oracle,
@@ -751,6 +758,9 @@ def main():
             fill_name = "fill_small_kernel<%d>" % (args.fill_threads or 256)
         if m["sub_batches"] == 1 and nbytes // max(n_obj, 1) < lim[1]:
             val_name = "validate_small_kernel<%d>" % (args.validate_threads or 256)
+        big = args.big_object_bytes if args.big_object_bytes >= 0 else _engine.BIG_OBJECT_BYTES_DEFAULT
+        if m["sub_batches"] == 1 and nbytes // max(n_obj, 1) >= big:
+            val_name = "validate_big_kernel"
         traffic, traffic_source = None, "none: not measured"
         if world == 1 and not args.no_traffic and not m["damaged"]:
             tail = ["--workload", args.workload, "--seed", str(args.seed), "--batch-gib", str(args.batch_gib),
@@ -760,6 +770,7 @@ def main():
             if args.fill_threads: tail += ["--fill-threads", str(args.fill_threads)]
             if args.validate_threads: tail += ["--validate-threads", str(args.validate_threads)]
             if args.small_object_bytes: tail += ["--small-object-bytes", args.small_object_bytes]
+            if args.big_object_bytes >= 0: tail += ["--big-object-bytes", str(args.big_object_bytes)]
             fk, vk = fill_name.split("<")[0], val_name.split("<")[0]
             traffic, traffic_source = measure_traffic(tail, {fk: m["n_fill"], vk: m["n_val"],
                                                              "warm_tables_kernel": m["n_fill"]})

@@ -365,6 +365,13 @@ int oval_ctx_set_tuning(oval_ctx* ctx, int fill_threads, int validate_threads);
 #define OVAL_SMALL_FILL_BYTES_DEFAULT 3072u
 #define OVAL_SMALL_VALIDATE_BYTES_DEFAULT 1280u
 int oval_set_small_object_bytes(uint64_t fill_bytes, uint64_t validate_bytes);
+/* Layouts whose objects average at least `validate_bytes` (multipart-sized
+ * bodies, s3client.go:164-236) are validated by the kernel that reads with one
+ * load per thread from workgroups of 1024 threads and looks its object up once
+ * per workgroup.  0 = every layout, UINT64_MAX = never.  Results are identical
+ * either way. */
+#define OVAL_BIG_VALIDATE_BYTES_DEFAULT (1ull << 20)
+int oval_set_big_object_bytes(uint64_t validate_bytes);
 
 /* ---- timing --------------------------------------------------------------
  * HIP events recorded on the context's stream, for callers (bench.py) that

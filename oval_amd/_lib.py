@@ -85,6 +85,7 @@ SIGNATURES = {
     "oval_device_count": (_int, [C.POINTER(_int)]),
     "oval_set_device_timeout_ms": (_int, [_u64]),
     "oval_set_small_object_bytes": (_int, [_u64, _u64]),
+    "oval_set_big_object_bytes": (_int, [_u64]),
     "oval_ctx_create": (_int, [_int, _vp, _pp]),
     "oval_ctx_destroy": (_int, [_vp]),
     "oval_ctx_sync": (_int, [_vp]),

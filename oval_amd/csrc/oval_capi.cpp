@@ -70,6 +70,7 @@ struct oval_layout {
     void*     chunk_desc_dev = nullptr;   // per-chunk descriptor copies, only while `one_level`
     bool      one_level = false;
     bool      small_fill = false, small_validate = false;   // objects of a few units: the kernels that resolve a chunk's objects at once
+    bool      big_validate = false;     // objects of megabytes: one lookup per workgroup of 1024 threads
     uint64_t  n_obj = 0;
     uint64_t  total_units = 0;
     uint64_t  span_bytes = 0;
@@ -162,6 +163,7 @@ namespace {
 std::atomic<uint64_t> g_device_timeout_ms{30000};
 std::atomic<uint64_t> g_small_fill_bytes{OVAL_SMALL_FILL_BYTES_DEFAULT};          // oval_set_small_object_bytes
 std::atomic<uint64_t> g_small_validate_bytes{OVAL_SMALL_VALIDATE_BYTES_DEFAULT};
+std::atomic<uint64_t> g_big_validate_bytes{OVAL_BIG_VALIDATE_BYTES_DEFAULT};      // oval_set_big_object_bytes
 thread_local bool g_wait_timed_out = false;
 
 uint64_t mono_ns()
@@ -246,6 +248,7 @@ oval::LayoutView view_of(const oval_layout* l)
     v.chunk_desc = l->one_level ? l->chunk_desc_dev : nullptr;
     v.small_fill = l->small_fill;
     v.small_validate = l->small_validate;
+    v.big_validate = l->big_validate;
     v.n_obj = (uint32_t)l->n_obj;
     v.n_tiles = l->n_tiles;
     v.span_units = (uint32_t)(l->span_bytes / OVAL_UNIT_SIZE);
@@ -297,6 +300,14 @@ int oval_set_small_object_bytes(uint64_t fill_bytes, uint64_t validate_bytes)
 try {
     g_small_fill_bytes.store(fill_bytes, std::memory_order_relaxed);
     g_small_validate_bytes.store(validate_bytes, std::memory_order_relaxed);
+    return OVAL_OK;
+} catch (...) {
+    return oval_internal_caught();
+}
+
+int oval_set_big_object_bytes(uint64_t validate_bytes)
+try {
+    g_big_validate_bytes.store(validate_bytes, std::memory_order_relaxed);
     return OVAL_OK;
 } catch (...) {
     return oval_internal_caught();
@@ -727,6 +738,7 @@ struct LayoutShape {
     uint32_t n_tiles = 0;
     bool one_level = false;
     bool small_fill = false, small_validate = false;
+    bool big_validate = false;
 };
 
 // First half of a rebuild: capacity (grow-only) and ordering against whatever
@@ -744,13 +756,14 @@ static int layout_prepare(oval_ctx* ctx, oval_layout* l, LayoutShape& sh, bool a
     sh.small_fill = sh.n_obj != 0 && avg_bytes < g_small_fill_bytes.load(std::memory_order_relaxed);
     sh.small_validate = sh.n_obj != 0 && avg_bytes < g_small_validate_bytes.load(std::memory_order_relaxed);
     sh.one_level = !sh.small_fill && sh.n_obj != 0 && avg_bytes < (256ull << 10);
+    sh.big_validate = sh.n_obj != 0 && avg_bytes >= g_big_validate_bytes.load(std::memory_order_relaxed);
     const uint64_t n_obj = sh.n_obj;
     const uint32_t n_tiles = sh.n_tiles;
     const bool one_level = sh.one_level;
     HIP_TRY(hipSetDevice(ctx->device));
     // Until every table is in place the layout describes nothing, so that a
     // failure below cannot leave counts that point into freed or missing tables.
-    l->n_obj = 0; l->n_tiles = 0; l->total_units = 0; l->span_bytes = 0; l->one_level = false; l->small_fill = false; l->small_validate = false; l->no_fill = false;
+    l->n_obj = 0; l->n_tiles = 0; l->total_units = 0; l->span_bytes = 0; l->one_level = false; l->small_fill = false; l->small_validate = false; l->big_validate = false; l->no_fill = false;
     const bool grow = n_obj > l->cap_obj || !l->descs_dev || n_tiles > l->cap_tiles || !l->chunk_first_dev ||
                       (one_level && (n_tiles > l->cap_desc_tiles || !l->chunk_desc_dev)) ||
                       sh.stage_bytes > l->cap_stage_bytes || sh.compact_bytes > l->cap_compact_bytes;
@@ -833,6 +846,7 @@ static int layout_finish(oval_layout* l, const LayoutShape& sh, hipStream_t buil
     l->one_level = sh.one_level;
     l->small_fill = sh.small_fill;
     l->small_validate = sh.small_validate;
+    l->big_validate = sh.big_validate;
     l->n_obj = sh.n_obj;
     l->no_fill = sh.no_fill;
     l->total_units = sh.total_units;

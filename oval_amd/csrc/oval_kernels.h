@@ -40,6 +40,9 @@ struct LayoutView {
     // objects of a few units: the kernels that look all objects of a chunk up at once (chosen per pass:
     // the fill gains from them up to larger objects than the validate pass does)
     bool            small_fill, small_validate;
+    // objects far larger than a workgroup's range: the validate kernel that reads with one load per thread from
+    // workgroups of 1024 threads and looks up once per workgroup
+    bool            big_validate;
 };
 
 struct LaunchCfg {

@@ -830,6 +830,91 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
 }
 
 // ---------------------------------------------------------------------------
+// Objects far larger than a workgroup's range (multipart-sized bodies).  A read
+// stream is served fastest here as ONE load per thread from workgroups of 1024
+// threads in address order (7.5 TB/s against 7.2 with four loads per thread,
+// tools/write_shapes.hip), which leaves a wavefront 1 KiB to pay its lookup
+// with: too little when every wavefront looks up for itself.  With objects of
+// megabytes nearly every workgroup's 16 KiB lie inside one object, so wavefront
+// 0 looks up once, leaves the sixteen lanes' expected bytes in LDS, and the
+// other fifteen wavefronts compare against those.  A workgroup whose range holds
+// an object boundary, a gap or a flagged descriptor, and any wavefront that sees
+// a mismatch, takes the walk below over its own four units.
+// ---------------------------------------------------------------------------
+// validate_chunk_walk for the four units [g4, g4 + 4) of one load: one walk with
+// the exact verdicts where a lane differs (a wavefront comes here on suspicion).
+__device__ __forceinline__ void validate_piece_walk(sdesc_ptr descs, uint32_t n_obj, uint32_t o0, uint32_t g4,
+                                                    const u32x4& v, oval_obj_result* __restrict__ results,
+                                                    unsigned long long* __restrict__ stripes, int lane)
+{
+    const int j = lane & 15;
+    const uint32_t g = g4 + ((uint32_t)lane >> 4);
+    const uint32_t gmul = (j == 2) ? 256u : 0u;
+    const uint32_t zwmask = (j == 2) ? 0u : 0xFFFFFFFFu;       // pattern.go:172 "Skip the unix time area."
+    const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
+                        filler_dword(4u * j + 3u)};
+    const uint32_t slots = lane_field_slots(j);
+    WRaw r;
+    WObj w;
+    w_fetch(descs, n_obj, o0, r);
+    w_activate(r, n_obj, w);
+    u32x4 tmpl = w_lane_template(w, j, cpat);
+    uint32_t force = w_lane_force(w, j);
+    WRun run = {kNone, 0, 0, kNone};
+    WTotals tot = {0, 0, 0, 0};
+    for (;;) {
+        const uint32_t ex = tmpl.x + g * gmul;
+        const bool bad = (g >= w.start && g < w.end) && ((w_diff(v, ex, tmpl, zwmask) | force) != 0u);
+        if (__any(bad)) w_handle_bad(v, ex, tmpl, w.lf, force, bad, j, slots, g4, run, tot);
+        if (w.end >= g4 + 4u) break;                             // kNone for "no more objects"
+        w_flush(results, stripes, w, run, tot, kNone, lane);     // (kNone: other wavefronts may hold units of the object too)
+        w_fetch(descs, n_obj, w.o + 1u, r);
+        w_activate(r, n_obj, w);
+        tmpl = w_lane_template(w, j, cpat);
+        force = w_lane_force(w, j);
+    }
+    if (w.o < n_obj) w_flush(results, stripes, w, run, tot, kNone, lane);
+    w_totals_flush(stripes, tot, lane);
+}
+
+constexpr uint32_t kBigThreads = 1024;                           // 16 wavefronts x 4 units = 64 units = 16 KiB = four chunks
+
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void validate_big_kernel(
+    sdesc_ptr descs, sidx_ptr chunk_first, uint32_t n_obj, uint32_t limit_units, const u32x4* __restrict__ body,
+    uint32_t chunk_begin, oval_obj_result* __restrict__ results, unsigned long long* __restrict__ stripes)
+{
+    __shared__ u32x4 s_tmpl[16];
+    __shared__ uint32_t s_one;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gw = (chunk_begin + blockIdx.x * 4u) * kUnitsPerChunk;     // the workgroup's first unit
+    const uint32_t g4 = gw + 4u * wv;
+    const uint32_t g = g4 + ((uint32_t)lane >> 4);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (g < limit_units) v = __builtin_nontemporal_load(body + (size_t)g4 * 16u + (uint32_t)lane);
+    if (wv == 0u) {
+        const u32x4 cpat = {filler_dword(4u * j), filler_dword(4u * j + 1u), filler_dword(4u * j + 2u),
+                            filler_dword(4u * j + 3u)};
+        WRaw r;
+        WObj w;
+        w_fetch(descs, n_obj, chunk_first[gw / kUnitsPerChunk], r);
+        w_activate(r, n_obj, w);
+        if (lane < 16) s_tmpl[lane] = w_lane_template(w, j, cpat);
+        // one object, without a flag that demands the exact check, holds every unit of the range
+        if (lane == 0) s_one = (w.start <= gw && w.end >= gw + kBigThreads / 16u && (w.lf >> 16) == 0u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_one != 0u) {
+        const u32x4 t = s_tmpl[j];
+        const uint32_t gmul = (j == 2) ? 256u : 0u;
+        const uint32_t zwmask = (j == 2) ? 0u : 0xFFFFFFFFu;   // pattern.go:172 "Skip the unix time area."
+        if (!__any(w_diff(v, t.x + g * gmul, t, zwmask) != 0u)) return;
+    }
+    validate_piece_walk(descs, n_obj, chunk_first[g4 / kUnitsPerChunk], g4, v, results, stripes, lane);
+}
+
+// ---------------------------------------------------------------------------
 // Small batches whose bodies live in pinned host memory (the micro-batched
 // single-object calls of the host mirror: Generate / Valid one 4-16 KiB object
 // per call, internal/runner/worker.go:64-200).  One launch does everything:
@@ -1204,7 +1289,10 @@ hipError_t launch_validate(hipStream_t s, const LaunchCfg& cfg, const LayoutView
         const uint32_t n_chunks = (t1 - t0) * kChunksPerTile;
 #define OVAL_LAUNCH_VAL(T)                                                                                              \
     do {                                                                                                                \
-        if (lv.small_validate)                                                                                          \
+        if (lv.big_validate)                                                                                            \
+            validate_big_kernel<<<n_chunks / 4u, kBigThreads, 0, s>>>(sd, cf, lv.n_obj, lv.span_units, b, chunk_begin,   \
+                                                                      results, tallies);                                \
+        else if (lv.small_validate)                                                                                     \
             validate_small_kernel<T><<<n_chunks / (T / 64), T, 0, s>>>(sd, static_cast<const u32x4*>(lv.descs), cf,      \
                                                                        lv.n_obj, lv.span_units, b, chunk_begin, results, \
                                                                        tallies);                                        \
@@ -1282,6 +1370,7 @@ hipError_t launch_validate_noalloc(hipStream_t s, int device, const LaunchCfg& c
     lv.total_units = 0;
     lv.small_fill = false;
     lv.small_validate = false;
+    lv.big_validate = false;
     if (lv.n_tiles > kNoAllocMaxTiles) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(tallies, 0, kTallyBytes, s);
     if (e != hipSuccess) return e;

@@ -32,6 +32,17 @@ def set_small_object_bytes(fill_bytes: int, validate_bytes: int | None = None) -
     check(_lib.lib().oval_set_small_object_bytes(fill_bytes, fill_bytes if validate_bytes is None else validate_bytes))
 
 
+BIG_OBJECT_BYTES_DEFAULT = 1 << 20             # OVAL_BIG_VALIDATE_BYTES_DEFAULT of include/oval_hip.h
+
+
+def set_big_object_bytes(validate_bytes: int) -> None:
+    """Layouts created or reset from now on whose objects average at least
+    `validate_bytes` take the validate kernel for multipart-sized bodies (one load
+    per thread, one lookup per workgroup of 1024 threads); 0 = every layout,
+    2**64 - 1 = never.  Results are identical either way."""
+    check(_lib.lib().oval_set_big_object_bytes(validate_bytes))
+
+
 class Context:
     """One device + one stream (oval_ctx)."""
 

@@ -60,10 +60,20 @@ def session_small_object_bytes():
     return (int(v, 0), int(v, 0)) if v else engine.SMALL_OBJECT_BYTES_DEFAULT
 
 
+def session_big_object_bytes():
+    """OVAL_TEST_BIG_OBJECT_BYTES=N likewise for the validate kernel for multipart-sized
+    bodies (layouts that average at least N bytes per object; 0: every layout)."""
+    from oval_amd import engine
+
+    v = os.environ.get("OVAL_TEST_BIG_OBJECT_BYTES")
+    return int(v, 0) if v else engine.BIG_OBJECT_BYTES_DEFAULT
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _small_object_selection():
-    if os.environ.get("OVAL_TEST_SMALL_OBJECT_BYTES"):
+    if os.environ.get("OVAL_TEST_SMALL_OBJECT_BYTES") or os.environ.get("OVAL_TEST_BIG_OBJECT_BYTES"):
         from oval_amd import engine
 
         engine.set_small_object_bytes(*session_small_object_bytes())
+        engine.set_big_object_bytes(session_big_object_bytes())
     yield

@@ -113,9 +113,14 @@ def main():
     ap.add_argument("--small-object-bytes", type=lambda v: int(v, 0), default=None,
                     help="layouts that average fewer bytes per object take the small-object kernels "
                          "(default: the library's limits; 0xFFFFFFFFFFFFFFFF: every layout)")
+    ap.add_argument("--big-object-bytes", type=lambda v: int(v, 0), default=None,
+                    help="layouts that average at least this many bytes per object take the validate kernel for "
+                         "multipart-sized bodies (default: the library's limit; 0: every layout)")
     args = ap.parse_args()
     if args.small_object_bytes is not None:
         engine.set_small_object_bytes(args.small_object_bytes)
+    if args.big_object_bytes is not None:
+        engine.set_big_object_bytes(args.big_object_bytes)
     oracle.build()
     ctx = engine.Context.on_torch_stream(0)
     seed_descs = build_descs("b", ["k"], [1], 1, T0, [256])
